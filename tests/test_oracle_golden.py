@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/cavi_oracle.py) against the golden vectors that
+tests/golden/make_golden.py captured by running the reference itself."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cavi_oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = sorted(glob.glob(os.path.join(HERE, "golden", "*_s*_k*.npz")))
+TOL = dict(rtol=1e-11, atol=1e-13)  # fp64 restatement vs fp64 reference
+
+
+def _load(path):
+    d = np.load(path)
+    meta = json.loads(str(d["meta"]))
+    return d, meta
+
+
+def _cfg(meta, max_iter, tol):
+    return dict(meta["base_cfg"], n_factors=meta["K"], random_state=meta["seed"],
+                max_iter=max_iter, tol=tol)
+
+
+STATE_KEYS = {
+    "poisson": ["a_theta", "b_theta", "a_beta", "b_beta", "E_theta", "E_beta"],
+    "hpf": ["gamma_a_theta", "gamma_b_theta", "gamma_a_beta", "gamma_b_beta", "gamma_b_xi",
+            "gamma_b_eta", "E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_xi", "gamma_a_eta"],
+    "gauss_bias": ["m_theta", "m_beta", "m_user_bias", "m_item_bias"],
+    "gauss": ["m_theta", "m_beta"],
+}
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+@pytest.mark.parametrize("vectorised", [False, True], ids=["rows", "segsum"])
+def test_states_after_n_iterations(path, vectorised):
+    d, meta = _load(path)
+    kind = meta["kind"]
+    tr = (d["train_u"], d["train_i"], d["train_rating"])
+    for n_it in meta["iters"]:
+        st, hist = orc.fit(kind, *tr, _cfg(meta, n_it, None if kind in ("poisson", "hpf") else 0.0),
+                           global_mean=float(d["global_mean"]), vectorised=vectorised)
+        assert hist["iterations"] == n_it
+        for key in STATE_KEYS[kind]:
+            np.testing.assert_allclose(st[key], d[f"it{n_it}_{key}"], **TOL, err_msg=f"{key}@{n_it}")
+        if kind.startswith("gauss"):
+            for side in ("V_theta", "V_beta"):
+                if f"it{n_it}_{side}" in d:
+                    np.testing.assert_allclose(st[side], d[f"it{n_it}_{side}"], **TOL)
+                else:
+                    np.testing.assert_allclose(np.einsum("nkk->nk", st[side]),
+                                               d[f"it{n_it}_{side}_diag"], **TOL)
+        if n_it == 3:
+            if kind.startswith("gauss"):
+                bias = kind == "gauss_bias"
+                p = orc.predict_dot(st["m_theta"], st["m_beta"], d["pred_u"], d["pred_i"],
+                                    st.get("m_user_bias"), st.get("m_item_bias"),
+                                    float(d["global_mean"]))
+                r, mm = orc.gaussian_eval(st, d["val_u"], d["val_i"], d["val_rating"],
+                                          float(d["global_mean"]), bias=bias)
+            else:
+                p = orc.predict_dot(st["E_theta"], st["E_beta"], d["pred_u"], d["pred_i"])
+                r, mm = orc.gamma_eval(st, d["val_u"], d["val_i"], d["val_rating"])
+            np.testing.assert_allclose(p, d["it3_predict"], **TOL)
+            np.testing.assert_allclose(r, float(d["it3_val_rmse"]), **TOL)
+            if "it3_val_macro_mae" in d:
+                np.testing.assert_allclose(mm, float(d["it3_val_macro_mae"]), **TOL)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_validation_trajectory_and_early_stop(path):
+    d, meta = _load(path)
+    kind = meta["kind"]
+    st, hist = orc.fit(kind, d["train_u"], d["train_i"], d["train_rating"],
+                       _cfg(meta, 40, meta["stop_tol"]),
+                       val=(d["val_u"], d["val_i"], d["val_rating"]),
+                       global_mean=float(d["global_mean"]), vectorised=True)
+    assert hist["iterations"] == int(d["stop_iterations_run"])
+    assert hist["stopped_early"] == bool(d["stop_early"])
+    np.testing.assert_allclose(hist["val_rmse"], d["stop_val_rmse"], rtol=1e-10)
+    if kind != "gauss":
+        np.testing.assert_allclose(hist["val_macro_mae"], d["stop_val_macro_mae"], rtol=1e-10)
+    for key in STATE_KEYS[kind]:
+        np.testing.assert_allclose(st[key], d[f"stop_{key}"], rtol=1e-9, atol=1e-12)
+
+
+def test_metrics_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "metrics.npz"))
+    assert orc.rmse(d["y_true"], d["y_pred"]) == pytest.approx(float(d["rmse"]), rel=1e-14)
+    assert orc.mae(d["y_true"], d["y_pred"]) == pytest.approx(float(d["mae"]), rel=1e-14)
+    assert orc.macro_mae(d["y_true"], d["y_pred"]) == pytest.approx(float(d["macro_mae"]), rel=1e-14)
+    assert orc.macro_mae(d["y_true"] - 4.4, d["y_pred"] - 4.4) == pytest.approx(
+        float(d["macro_mae_centered"]), rel=1e-14)
+
+
+def test_medium_c1_shape(golden_dir):
+    """BASELINE config #1 (10k x 2k, 200k ratings, K=16), 2 iterations."""
+    d = np.load(os.path.join(golden_dir, "medium_c1.npz"))
+    u, i, r = d["u"].astype(np.int64), d["i"].astype(np.int64), d["rating"].astype(np.float64)
+    base = {"hpf": dict(a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0),
+            "poisson": dict(a0=0.1, b0=0.5),
+            "gauss_bias": dict(sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0)}
+    for kind in ("hpf", "poisson", "gauss_bias"):
+        x = r.copy()
+        gm = float(d[f"{kind}_global_mean"])
+        if kind == "hpf":
+            x += 1
+        elif kind == "gauss_bias":
+            x -= gm
+        st, _ = orc.fit(kind, u, i, x, dict(base[kind], n_factors=16, random_state=42, max_iter=2,
+                                            tol=None if kind != "gauss_bias" else 0.0),
+                        global_mean=gm, vectorised=True)
+        A, B = (st["m_theta"], st["m_beta"]) if kind == "gauss_bias" else (st["E_theta"], st["E_beta"])
+        np.testing.assert_allclose(A[d["rows_u"]], d[f"{kind}_A_rows"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(B[d["rows_i"]], d[f"{kind}_B_rows"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(A.sum(), float(d[f"{kind}_A_sum"]), rtol=1e-9)
+        np.testing.assert_allclose(np.abs(B).sum(), float(d[f"{kind}_B_abs"]), rtol=1e-9)
+        if kind == "gauss_bias":
+            np.testing.assert_allclose(st["V_theta"][d["rows_u"][:16]], d[f"{kind}_Vtheta_rows"],
+                                       rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(st["m_user_bias"].sum(), float(d[f"{kind}_bias_u_sum"]), rtol=1e-9)

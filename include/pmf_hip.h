@@ -1,0 +1,215 @@
+/*
+ * pmf_hip.h -- C-ABI of libpmf_hip.so: the MI355X (gfx950) engine for the
+ * latent-factor update loop of rogeliolopezcamara/prob-matrix-factorization.
+ *
+ * The reference has no FFI of its own: its hot path is the body of
+ * `fit()` / `predict()` / `evaluate_rmse()` of the classes in src/models/ (pure NumPy).
+ * This header is the boundary a replacement binds instead: every entry point
+ * names the reference code it stands in for (paths relative to the reference
+ * repository root).  The binding a maintainer adds on the reference side is a
+ * ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types, caller-owned host buffers, 64-bit sizes, no torch types;
+ *   - every function returns 0 on success and a negative PMF_E* code on
+ *     failure; pmf_last_error() returns a thread-local message.  Nothing
+ *     aborts or throws across the ABI;
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe;
+ *     distinct contexts are independent;
+ *   - host <-> device exchange of model state is always float64 (the
+ *     reference's dtype); device storage is the
+ *     context's dtype (PMF_F32 for throughput, PMF_F64 for parity runs).
+ */
+#ifndef PMF_HIP_H
+#define PMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMF_ABI_VERSION 1
+
+/* error codes */
+#define PMF_OK 0
+#define PMF_EINVAL (-1)   /* bad argument / state not set */
+#define PMF_EHIP (-2)     /* a HIP runtime call failed (message has the hipError string) */
+#define PMF_ENOMEM (-3)
+#define PMF_ERANGE (-4)   /* id outside [0, n_rows) or unsupported n_factors */
+
+/* device storage / arithmetic type of a context */
+#define PMF_F32 0
+#define PMF_F64 1
+
+/* which block of the bipartite model a call addresses */
+#define PMF_SIDE_USER 0
+#define PMF_SIDE_ITEM 1
+
+/* Model-state arrays (second argument of pmf_set_array / pmf_get_array).
+ * Reference attribute each one mirrors:
+ *   FACTOR   E_theta / E_beta        (poisson_mf_cavi.py:41-42, hpf_cavi.py:54-55)
+ *            m_theta / m_beta        (gaussian_mf_cavi_bias.py:33,35)        [rows x K]
+ *   SHAPE    a_theta / a_beta, gamma_a_theta / gamma_a_beta                  [rows x K]
+ *   RATE     b_theta / b_beta, gamma_b_theta / gamma_b_beta                  [rows x K]
+ *   PRIOR_RATE  E_xi / E_eta         (hpf_cavi.py:56-57)                     [rows]
+ *   HYPER_RATE  gamma_b_xi / gamma_b_eta (hpf_cavi.py:46,50)                 [rows]
+ *   COV      V_theta / V_beta        (gaussian_mf_cavi_bias.py:34,36)        [rows x K x K] on the
+ *            host side; packed lower-triangular K(K+1)/2 per row on the device
+ *   BIAS     m_user_bias / m_item_bias (gaussian_mf_cavi_bias.py:39-40)      [rows]
+ */
+#define PMF_ARR_FACTOR 0
+#define PMF_ARR_SHAPE 1
+#define PMF_ARR_RATE 2
+#define PMF_ARR_PRIOR_RATE 3
+#define PMF_ARR_HYPER_RATE 4
+#define PMF_ARR_COV 5
+#define PMF_ARR_BIAS 6
+#define PMF_ARR_COUNT 7
+
+/* kernel classes for pmf_prof_get (live hipEvent timing on the context's stream) */
+#define PMF_KERNEL_GAMMA_SWEEP 0   /* Poisson/HPF half-sweep accumulate(+finalise) */
+#define PMF_KERNEL_GAMMA_FINAL 1   /* split-row / distributed finalise */
+#define PMF_KERNEL_GAUSS_ACCUM 2   /* Gaussian normal-equation accumulate */
+#define PMF_KERNEL_GAUSS_SOLVE 3   /* K x K SPD inverse + mean */
+#define PMF_KERNEL_GAUSS_BIAS 4    /* Gaussian bias half-sweep */
+#define PMF_KERNEL_EVAL 5          /* fused predict + error reduction */
+#define PMF_KERNEL_PREDICT 6
+#define PMF_KERNEL_TOPK 7
+#define PMF_KERNEL_COUNT 8
+
+typedef struct pmf_ctx pmf_ctx;
+
+/* ---- library ----------------------------------------------------------- */
+int pmf_abi_version(void);
+const char *pmf_last_error(void);
+/* number of visible HIP devices (0 and PMF_EHIP when there is no usable GPU) */
+int pmf_device_count(int *count);
+
+/* ---- context ------------------------------------------------------------
+ * One context = one model instance's device state on one GPU.
+ * n_users / n_items follow `_infer_dimensions` (hpf_cavi.py:60-64): max id + 1
+ * of the TRAINING ratings.  In a multi-GPU run n_users is the size of this
+ * rank's user range (ids are local to it) and n_items is global. */
+int pmf_ctx_create(int device, int64_t n_users, int64_t n_items, int n_factors, int dtype,
+                   pmf_ctx **out);
+int pmf_ctx_destroy(pmf_ctx *ctx);
+/* run on an existing HIP stream (e.g. torch's current stream) instead of the
+ * context's own; `hip_stream` is a hipStream_t.  NULL restores the own stream. */
+int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream);
+int pmf_ctx_sync(pmf_ctx *ctx);
+/* bytes of device memory currently held by the context */
+int pmf_ctx_device_bytes(pmf_ctx *ctx, int64_t *bytes);
+
+/* Training ratings in their original order (COO).  Replaces
+ * `_build_index_lists` (hpf_cavi.py:97-107, gaussian_mf_cavi_bias.py:69-86):
+ * builds the by-user (CSR) and by-item (CSC) orderings with a stable counting
+ * sort, so every row lists its ratings in ascending original position and
+ * duplicate (u,i) pairs are kept.  Also builds the per-side work lists
+ * (row chunks) the sweep kernels consume. */
+int pmf_ctx_set_ratings(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids,
+                        const int32_t *item_ids, const double *ratings);
+
+/* Host float64 -> device (and back).  `host` holds rows x K (FACTOR, SHAPE,
+ * RATE), rows (PRIOR_RATE, HYPER_RATE, BIAS) or rows x K x K (COV) doubles,
+ * C-contiguous.  Setting an array allocates it. */
+int pmf_set_array(pmf_ctx *ctx, int side, int array, const double *host);
+int pmf_get_array(pmf_ctx *ctx, int side, int array, double *host);
+/* COV shortcut for `_initialize_variational_params`
+ * (gaussian_mf_cavi_bias.py:64-67): every row's covariance = scale * I. */
+int pmf_set_cov_identity(pmf_ctx *ctx, int side, double scale);
+
+/* ---- Poisson MF / HPF half-sweep ---------------------------------------
+ * One block-Jacobi half-sweep over all rows of `side`
+ * (poisson_mf_cavi.py:135-167 users, :173-197 items;
+ *  hpf_cavi.py:126-153 users, :162-187 items):
+ *     rate_j    = max(FACTOR_other[o_j] . FACTOR_side[r], 1e-10)
+ *     SHAPE[r]  = shape_prior + sum_j x_j * FACTOR_other[o_j] * FACTOR_side[r] / rate_j
+ *     RATE[r]   = rate_prior_r + sum_j FACTOR_other[o_j]
+ *     FACTOR[r] = SHAPE[r] / RATE[r]
+ * rate_prior_r is `rate_prior` when hierarchical == 0 (Poisson MF, b0) and
+ * PRIOR_RATE[r] (E_xi / E_eta) when hierarchical != 0 (HPF).  In the
+ * hierarchical case the epilogue also performs the xi / eta update of
+ * hpf_cavi.py:155-159 / :189-193:
+ *     HYPER_RATE[r] = hyper_rate_prior + sum_k FACTOR[r,k]
+ *     PRIOR_RATE[r] = hyper_shape / HYPER_RATE[r]
+ * Rows without ratings fall back to the priors (hpf_cavi.py:128-132). */
+int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior,
+                    int hierarchical, double hyper_shape, double hyper_rate_prior);
+
+/* Multi-GPU form of the same half-sweep (ratings sharded by user range,
+ * SURVEY.md section 8e).  `accumulate` writes this rank's raw sums
+ * [rows x 2 x Kpad] (shape sums, then rate sums; Kpad from pmf_ctx_kpad) into
+ * `stats_dev`, a DEVICE buffer the caller owns and all-reduces (RCCL) between
+ * the two calls; `finalize` applies the priors and the epilogue above. */
+int pmf_ctx_kpad(pmf_ctx *ctx, int *kpad);
+int pmf_gamma_accumulate(pmf_ctx *ctx, int side, void *stats_dev);
+int pmf_gamma_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double shape_prior,
+                       double rate_prior, int hierarchical, double hyper_shape,
+                       double hyper_rate_prior);
+
+/* ---- Gaussian MF half-sweeps -------------------------------------------
+ * Factor half-sweep (gaussian_mf_cavi_bias.py:132-165 users, :170-201 items;
+ * bias-free twin gaussian_mf_cavi.py:121-147 / :152-178 when no BIAS array is
+ * set): for every row with at least one rating
+ *     S      = sum_j ( COV_other[o_j] + FACTOR_other[o_j] FACTOR_other[o_j]^T )
+ *     COV[r] = inv( I/eta2 + S/sigma2 )
+ *     FACTOR[r] = (1/sigma2) COV[r] . sum_j FACTOR_other[o_j] (x_j - BIAS_side[r] - BIAS_other[o_j])
+ * Rows without ratings keep their mean and covariance. */
+int pmf_gauss_factor_sweep(pmf_ctx *ctx, int side, double sigma2, double eta2);
+/* Bias half-sweep (gaussian_mf_cavi_bias.py:206-232 users, :237-263 items):
+ *     BIAS[r] = var/sigma2 * sum_j (x_j - BIAS_other[o_j] - FACTOR_other[o_j].FACTOR_side[r]),
+ *     var = 1 / (1/eta_bias2 + n_r/sigma2);   rows without ratings keep their value. */
+int pmf_gauss_bias_sweep(pmf_ctx *ctx, int side, double sigma2, double eta_bias2);
+
+/* Multi-GPU forms: raw per-row sums into / from a caller-owned DEVICE buffer.
+ * Factor: [rows x (Kp + Kpad)] = packed lower triangle of S, then the
+ * right-hand side (Kp = K(K+1)/2 rounded up to a multiple of 4, see
+ * pmf_ctx_cov_stride).  Bias: [rows x 2] = residual sum, rating count. */
+int pmf_ctx_cov_stride(pmf_ctx *ctx, int *stride);
+int pmf_gauss_factor_accumulate(pmf_ctx *ctx, int side, void *stats_dev);
+int pmf_gauss_factor_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,
+                              double eta2);
+int pmf_gauss_bias_accumulate(pmf_ctx *ctx, int side, void *stats_dev);
+int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,
+                            double eta_bias2);
+
+/* ---- predict / evaluate -------------------------------------------------
+ * `predict` (hpf_cavi.py:215-231, poisson_mf_cavi.py:221-241,
+ * gaussian_mf_cavi_bias.py:291-316): out[n] = FACTOR_user[u].FACTOR_item[i]
+ * (+ BIAS_user[u] + BIAS_item[i] when use_bias) for ids inside the trained
+ * dimensions, 0 otherwise; `offset` (global_mean) is added to every row. */
+int pmf_predict(pmf_ctx *ctx, int64_t n, const int32_t *user_ids, const int32_t *item_ids,
+                int use_bias, double offset, double *out);
+
+/* Validation set kept on the device for the per-iteration monitor of `fit`
+ * (hpf_cavi.py:196-211, gaussian_mf_cavi_bias.py:268-284).  `label_index[n]`
+ * maps each true rating to its position in np.unique(y_true) (n_labels <= 32)
+ * for the per-label error sums of metrics.macro_mae (metrics.py:37-51). */
+int pmf_eval_set(pmf_ctx *ctx, int64_t n, const int32_t *user_ids, const int32_t *item_ids,
+                 const double *y_true, const int32_t *label_index, int n_labels);
+/* Fused predict + reduction over the stored validation set: sum of squared
+ * errors, per-label sum of |error| and per-label counts.  The host finishes
+ * rmse = sqrt(sse / n) (metrics.py:6-10) and macro_mae = mean_l(abs_l / cnt_l). */
+int pmf_eval_run(pmf_ctx *ctx, int use_bias, double offset, double *sum_sq_err,
+                 double *abs_err_per_label, int64_t *count_per_label);
+
+/* Top-k items per user from the dense reconstruction FACTOR_user . FACTOR_item^T
+ * (the "identical top-k item rankings" check of the north star; the reference
+ * has no ranking API -- scores follow `predict`, ties broken by lower item id).
+ * out_items / out_scores hold n_query x k entries. */
+int pmf_topk_items(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int k, int use_bias,
+                   int32_t *out_items, double *out_scores);
+
+/* ---- profiling ----------------------------------------------------------
+ * When enabled every kernel launch is bracketed by hipEvents on the context's
+ * stream; pmf_prof_get synchronises and returns the accumulated device time
+ * and launch count of one kernel class. */
+int pmf_prof_enable(pmf_ctx *ctx, int enable);
+int pmf_prof_reset(pmf_ctx *ctx);
+int pmf_prof_get(pmf_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMF_HIP_H */

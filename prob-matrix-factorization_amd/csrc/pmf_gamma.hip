@@ -1,0 +1,337 @@
+// Poisson MF / HPF half-sweep kernels (rows a5, a6, a7 of SURVEY.md section 8).
+//
+// Work decomposition: a *lane group* of LPR = pow2(Kpad/4) lanes owns one task
+// (a run of at most PMF_GAMMA_CHUNK ratings of one row); lane c of the group
+// owns factor elements [4c, 4c+4) of every K-vector it touches, so one gathered
+// factor row is one 16-byte access per lane and a wavefront gathers 64/LPR rows
+// per instruction (K = 64 fp32: 4 rows x 256 B = one full 1-KiB wave access).
+// The K-length dot product is a 4-FMA partial per lane + a DPP reduction inside
+// the group; shape/rate sums live in registers for the whole task, so every
+// rating costs exactly one index, one value and one gathered row of HBM traffic.
+// No atomics: rows that exceed one chunk write per-chunk partial sums that a
+// second kernel adds in chunk order, so results are bitwise reproducible.
+#include "pmf_device.h"
+
+template <typename T>
+struct GammaParams {
+    const PmfTask *tasks;
+    int64_t n_tasks;
+    const PmfSplitRow *split;
+    const int32_t *other;
+    const T *val;
+    T *factor_self;
+    const T *factor_other;
+    T *shape;
+    T *rate;
+    T *prior_rate_vec;  // E_xi / E_eta (HPF) or null
+    T *hyper_rate;      // gamma_b_xi / gamma_b_eta (HPF) or null
+    T *partial;         // [n_slots][2][kpad]
+    T *stats;           // [rows][2][kpad], STATS mode only
+    T shape_prior, rate_prior, hyper_shape, hyper_rate_prior;
+    int hierarchical;
+    int K, kpad;
+    int64_t rows;
+};
+
+// shape = prior + sum, rate = prior_rate + sum, E = shape / rate, plus the
+// xi / eta update (hpf_cavi.py:155-159) when hierarchical.
+template <typename T, int LPR>
+__device__ __forceinline__ void gamma_finalize_row(const GammaParams<T> &p, int row, int c, bool active,
+                                                   const Vec4<T> &sum_a, const Vec4<T> &sum_b) {
+    const int koff = c * PMF_VEC;
+    const T rp = p.hierarchical ? p.prior_rate_vec[row] : p.rate_prior;
+    Vec4<T> sh, rt, ex;
+    T esum = (T)0;
+#pragma unroll
+    for (int e = 0; e < PMF_VEC; ++e) {
+        const bool ok = active && (koff + e) < p.K;
+        T s = p.shape_prior + sum_a.v[e];
+        T r = rp + sum_b.v[e];
+        T x = s / r;
+        sh.v[e] = ok ? s : (T)0;
+        rt.v[e] = ok ? r : (T)0;
+        ex.v[e] = ok ? x : (T)0;
+        esum += ex.v[e];
+    }
+    if (active) {
+        const int64_t at = (int64_t)row * p.kpad + koff;
+        store4(p.shape + at, sh);
+        store4(p.rate + at, rt);
+        store4(p.factor_self + at, ex);
+    }
+    if (p.hierarchical) {
+        esum = group_sum<LPR>(esum);
+        if (c == 0) {
+            T hr = p.hyper_rate_prior + esum;
+            p.hyper_rate[row] = hr;
+            p.prior_rate_vec[row] = p.hyper_shape / hr;
+        }
+    }
+}
+
+template <typename T, int LPR, bool STATS>
+__global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
+    constexpr int G = 256 / LPR;
+    constexpr int UN = LPR < 4 ? LPR : 4;
+    const int c = threadIdx.x % LPR;
+    const int64_t task_id = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
+    if (task_id >= p.n_tasks) return;
+    const PmfTask t = p.tasks[task_id];
+    const int koff = c * PMF_VEC;
+    const bool active = koff < p.kpad;
+    const int kpad = p.kpad;
+
+    Vec4<T> self = active ? load4(p.factor_self + (int64_t)t.row * kpad + koff) : zero4<T>();
+    Vec4<T> acc_a = zero4<T>(), acc_b = zero4<T>();
+    const int32_t *col = p.other + t.start;
+    const T *val = p.val + t.start;
+
+    for (int base = 0; base < t.len; base += LPR) {
+        const int n = min(LPR, t.len - base);
+        int my_o = 0;
+        T my_x = (T)0;
+        if (c < n) {
+            my_o = col[base + c];
+            my_x = val[base + c];
+        }
+        for (int tt = 0; tt < n; tt += UN) {
+            int o[UN];
+            T xv[UN];
+            Vec4<T> b[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                o[q] = __shfl(my_o, tt + q, LPR);
+                xv[q] = __shfl(my_x, tt + q, LPR);
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+                b[q] = active ? load4(p.factor_other + (int64_t)o[q] * kpad + koff) : zero4<T>();
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                if (tt + q < n) {
+                    T d = b[q].v[0] * self.v[0];
+                    d = fma(b[q].v[1], self.v[1], d);
+                    d = fma(b[q].v[2], self.v[2], d);
+                    d = fma(b[q].v[3], self.v[3], d);
+                    d = group_sum<LPR>(d);
+                    d = vmax(d, (T)PMF_RATE_FLOOR);
+                    const T w = xv[q] / d;
+#pragma unroll
+                    for (int e = 0; e < PMF_VEC; ++e) {
+                        acc_a.v[e] += (w * b[q].v[e]) * self.v[e];
+                        acc_b.v[e] += b[q].v[e];
+                    }
+                }
+            }
+        }
+    }
+
+    if (t.slot >= 0) {
+        if (active) {
+            T *dst = p.partial + (int64_t)t.slot * 2 * kpad + koff;
+            store4(dst, acc_a);
+            store4(dst + kpad, acc_b);
+        }
+    } else if (STATS) {
+        if (active) {
+            T *dst = p.stats + (int64_t)t.row * 2 * kpad + koff;
+            store4(dst, acc_a);
+            store4(dst + kpad, acc_b);
+        }
+    } else {
+        gamma_finalize_row<T, LPR>(p, t.row, c, active, acc_a, acc_b);
+    }
+}
+
+// One block per split row: group g adds slots g, g+G, ... in order, the G
+// group sums are then added in group order by group 0 (fixed order => bitwise
+// reproducible), which finalises the row (or writes its raw sums in STATS mode).
+template <typename T, int LPR, bool STATS>
+__global__ __launch_bounds__(256) void gamma_split_kernel(GammaParams<T> p) {
+    constexpr int G = 256 / LPR;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);  // [G][2][kpad]
+    const PmfSplitRow sr = p.split[blockIdx.x];
+    const int c = threadIdx.x % LPR;
+    const int g = threadIdx.x / LPR;
+    const int koff = c * PMF_VEC;
+    const int kpad = p.kpad;
+    const bool active = koff < kpad;
+    Vec4<T> sa = zero4<T>(), sb = zero4<T>();
+    if (active) {
+        for (int s = g; s < sr.n_slots; s += G) {
+            const T *src = p.partial + (int64_t)(sr.first_slot + s) * 2 * kpad + koff;
+            Vec4<T> a = load4(src), b = load4(src + kpad);
+#pragma unroll
+            for (int e = 0; e < PMF_VEC; ++e) {
+                sa.v[e] += a.v[e];
+                sb.v[e] += b.v[e];
+            }
+        }
+        store4(smem + (int64_t)g * 2 * kpad + koff, sa);
+        store4(smem + (int64_t)g * 2 * kpad + kpad + koff, sb);
+    }
+    __syncthreads();
+    if (g != 0) return;
+    sa = zero4<T>();
+    sb = zero4<T>();
+    if (active) {
+        const int ng = min(G, sr.n_slots);
+        for (int s = 0; s < ng; ++s) {
+            Vec4<T> a = load4(smem + (int64_t)s * 2 * kpad + koff);
+            Vec4<T> b = load4(smem + (int64_t)s * 2 * kpad + kpad + koff);
+#pragma unroll
+            for (int e = 0; e < PMF_VEC; ++e) {
+                sa.v[e] += a.v[e];
+                sb.v[e] += b.v[e];
+            }
+        }
+    }
+    if (STATS) {
+        if (active) {
+            T *dst = p.stats + (int64_t)sr.row * 2 * kpad + koff;
+            store4(dst, sa);
+            store4(dst + kpad, sb);
+        }
+    } else {
+        gamma_finalize_row<T, LPR>(p, sr.row, c, active, sa, sb);
+    }
+}
+
+// STATS mode, after the all-reduce: every row from its summed statistics.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void gamma_finalize_all_kernel(GammaParams<T> p) {
+    constexpr int G = 256 / LPR;
+    const int c = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
+    if (row >= p.rows) return;
+    const int koff = c * PMF_VEC;
+    const bool active = koff < p.kpad;
+    Vec4<T> sa = zero4<T>(), sb = zero4<T>();
+    if (active) {
+        const T *src = p.stats + row * 2 * p.kpad + koff;
+        sa = load4(src);
+        sb = load4(src + p.kpad);
+    }
+    gamma_finalize_row<T, LPR>(p, (int)row, c, active, sa, sb);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T, int LPR>
+static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, int mode /*0 fused, 1 accumulate, 2 finalize*/) {
+    constexpr int G = 256 / LPR;
+    const PmfTaskList &tl = ctx->index[side].gamma_tasks;
+    if (mode == 0 || mode == 1) {
+        if (tl.n_tasks > 0) {
+            PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_SWEEP);
+            dim3 grid((unsigned)((tl.n_tasks + G - 1) / G));
+            if (mode == 0)
+                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, false>), grid, dim3(256), 0, ctx->stream, p);
+            else
+                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, true>), grid, dim3(256), 0, ctx->stream, p);
+        }
+        if (tl.n_split > 0) {
+            PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_FINAL);
+            size_t smem = (size_t)G * 2 * ctx->kpad * sizeof(T);
+            if (mode == 0)
+                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, false>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
+            else
+                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, true>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
+        }
+    } else {
+        PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_FINAL);
+        dim3 grid((unsigned)((p.rows + G - 1) / G));
+        hipLaunchKernelGGL((gamma_finalize_all_kernel<T, LPR>), grid, dim3(256), 0, ctx->stream, p);
+    }
+    PMF_HIP_CHECK(hipGetLastError());
+    return PMF_OK;
+}
+
+template <typename T>
+static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape_prior, double rate_prior,
+                     int hierarchical, double hyper_shape, double hyper_rate_prior) {
+    const int other = 1 - side;
+    const PmfSideIndex &ix = ctx->index[side];
+    const PmfTaskList &tl = ix.gamma_tasks;
+    int rc;
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gamma_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, other, PMF_ARR_FACTOR, "pmf_gamma_sweep"))) return rc;
+    PMF_REQUIRE(ix.d_ptr, PMF_EINVAL, "pmf_gamma_sweep: ratings have not been set");
+    if (mode != 1) {
+        if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_SHAPE))) return rc;
+        if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_RATE))) return rc;
+        if (hierarchical) {
+            if ((rc = pmf_require_array(ctx, side, PMF_ARR_PRIOR_RATE, "pmf_gamma_sweep (hierarchical)"))) return rc;
+            if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_HYPER_RATE))) return rc;
+        }
+    }
+    if (mode != 2 && tl.n_slots > 0)
+        if ((rc = pmf_ensure_partial(ctx, (size_t)tl.n_slots * 2 * ctx->kpad * sizeof(T)))) return rc;
+
+    GammaParams<T> p;
+    p.tasks = tl.d_tasks;
+    p.n_tasks = tl.n_tasks;
+    p.split = tl.d_split;
+    p.other = ix.d_other;
+    p.val = (const T *)ix.d_val;
+    p.factor_self = (T *)ctx->arr[side][PMF_ARR_FACTOR];
+    p.factor_other = (const T *)ctx->arr[other][PMF_ARR_FACTOR];
+    p.shape = (T *)ctx->arr[side][PMF_ARR_SHAPE];
+    p.rate = (T *)ctx->arr[side][PMF_ARR_RATE];
+    p.prior_rate_vec = (T *)ctx->arr[side][PMF_ARR_PRIOR_RATE];
+    p.hyper_rate = (T *)ctx->arr[side][PMF_ARR_HYPER_RATE];
+    p.partial = (T *)ctx->d_partial;
+    p.stats = (T *)stats;
+    p.shape_prior = (T)shape_prior;
+    p.rate_prior = (T)rate_prior;
+    p.hyper_shape = (T)hyper_shape;
+    p.hyper_rate_prior = (T)hyper_rate_prior;
+    p.hierarchical = hierarchical;
+    p.K = ctx->K;
+    p.kpad = ctx->kpad;
+    p.rows = ctx->rows[side];
+
+    switch (pmf_lanes_per_row(ctx->kpad)) {
+        case 1: return launch_gamma<T, 1>(ctx, side, p, mode);
+        case 2: return launch_gamma<T, 2>(ctx, side, p, mode);
+        case 4: return launch_gamma<T, 4>(ctx, side, p, mode);
+        case 8: return launch_gamma<T, 8>(ctx, side, p, mode);
+        case 16: return launch_gamma<T, 16>(ctx, side, p, mode);
+        case 32: return launch_gamma<T, 32>(ctx, side, p, mode);
+        case 64: return launch_gamma<T, 64>(ctx, side, p, mode);
+    }
+    pmf_set_error("pmf_gamma_sweep: unsupported n_factors %d", ctx->K);
+    return PMF_ERANGE;
+}
+
+#define GAMMA_PROLOGUE(fn)                                                                              \
+    PMF_REQUIRE(ctx != nullptr, PMF_EINVAL, fn ": null context");                                       \
+    PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, fn ": bad side %d", side);  \
+    PMF_HIP_CHECK(hipSetDevice(ctx->device));
+
+extern "C" int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior,
+                               int hierarchical, double hyper_shape, double hyper_rate_prior) {
+    GAMMA_PROLOGUE("pmf_gamma_sweep");
+    if (ctx->dtype == PMF_F64)
+        return run_gamma<double>(ctx, side, 0, nullptr, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+    return run_gamma<float>(ctx, side, 0, nullptr, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+}
+
+extern "C" int pmf_gamma_accumulate(pmf_ctx *ctx, int side, void *stats_dev) {
+    GAMMA_PROLOGUE("pmf_gamma_accumulate");
+    PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gamma_accumulate: null stats buffer");
+    if (ctx->dtype == PMF_F64) return run_gamma<double>(ctx, side, 1, stats_dev, 0, 0, 0, 0, 0);
+    return run_gamma<float>(ctx, side, 1, stats_dev, 0, 0, 0, 0, 0);
+}
+
+extern "C" int pmf_gamma_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double shape_prior,
+                                  double rate_prior, int hierarchical, double hyper_shape,
+                                  double hyper_rate_prior) {
+    GAMMA_PROLOGUE("pmf_gamma_finalize");
+    PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gamma_finalize: null stats buffer");
+    if (ctx->dtype == PMF_F64)
+        return run_gamma<double>(ctx, side, 2, (void *)stats_dev, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+    return run_gamma<float>(ctx, side, 2, (void *)stats_dev, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+}

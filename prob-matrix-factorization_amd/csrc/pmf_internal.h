@@ -1,0 +1,151 @@
+// Internal declarations shared by the translation units of libpmf_hip.so.
+// gfx950 only: wave64, 16-byte vector accesses, DPP row reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "pmf_hip.h"
+
+#define PMF_WAVE 64
+#define PMF_VEC 4               // elements per lane access (16 B fp32 / 32 B fp64)
+#define PMF_RATE_FLOOR 1e-10    // hpf_cavi.py:141
+#define PMF_MAX_LABELS 32
+
+void pmf_set_error(const char *fmt, ...);
+
+#define PMF_HIP_CHECK(expr)                                                         \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            pmf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                          __FILE__, __LINE__);                                      \
+            return PMF_EHIP;                                                        \
+        }                                                                           \
+    } while (0)
+
+#define PMF_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            pmf_set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+// One unit of sweep work: a contiguous run of one row's ratings.
+// slot < 0  : the run is the whole row  -> the kernel finalises the row itself
+// slot >= 0 : the row is split          -> raw sums go to partial slot `slot`
+struct PmfTask {
+    int64_t start;   // offset into the side's col/val arrays
+    int32_t row;
+    int32_t len;
+    int32_t slot;
+    int32_t pad;
+};
+
+// A row whose ratings were split over several tasks (heavy rows).
+struct PmfSplitRow {
+    int32_t row;
+    int32_t first_slot;
+    int32_t n_slots;
+    int32_t pad;
+};
+
+struct PmfTaskList {
+    int64_t n_tasks = 0;
+    int64_t n_slots = 0;
+    int64_t n_split = 0;
+    int32_t max_len = 0;
+    PmfTask *d_tasks = nullptr;
+    PmfSplitRow *d_split = nullptr;
+};
+
+// Ratings ordered by one side (CSR when side = user, CSC when side = item).
+struct PmfSideIndex {
+    int64_t *d_ptr = nullptr;    // [rows + 1]
+    int32_t *d_other = nullptr;  // [nnz] id on the opposite side
+    void *d_val = nullptr;       // [nnz] rating, context dtype
+    std::vector<int64_t> h_ptr;  // host copy of ptr (task building)
+    PmfTaskList gamma_tasks;     // chunk = PMF_GAMMA_CHUNK, empty rows included
+    PmfTaskList gauss_tasks;     // chunk = PMF_GAUSS_CHUNK, empty rows excluded
+    PmfTaskList bias_tasks;      // chunk = PMF_GAMMA_CHUNK, empty rows excluded
+};
+
+struct PmfEvalSet {
+    int64_t n = 0;
+    int n_labels = 0;
+    int32_t *d_u = nullptr;
+    int32_t *d_i = nullptr;
+    double *d_y = nullptr;
+    int32_t *d_label = nullptr;
+};
+
+struct pmf_ctx {
+    int device = 0;
+    int dtype = PMF_F32;
+    int64_t rows[2] = {0, 0};
+    int K = 0;
+    int kpad = 0;        // K rounded up to PMF_VEC
+    int kp = 0;          // K(K+1)/2
+    int cov_stride = 0;  // kp rounded up to PMF_VEC
+    int64_t nnz = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    size_t elem = 4;
+
+    void *arr[2][PMF_ARR_COUNT] = {};
+    PmfSideIndex index[2];
+    PmfEvalSet eval;
+
+    // scratch, grown on demand
+    void *d_partial = nullptr;
+    size_t partial_bytes = 0;
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *h_pinned = nullptr;
+    size_t pinned_bytes = 0;
+
+    int64_t device_bytes = 0;
+
+    bool prof = false;
+    struct ProfRec {
+        hipEvent_t a, b;
+        int kernel;
+    };
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[PMF_KERNEL_COUNT] = {};
+    int64_t prof_n[PMF_KERNEL_COUNT] = {};
+};
+
+#define PMF_GAMMA_CHUNK 256
+#define PMF_GAUSS_CHUNK 128
+
+int pmf_dev_alloc(pmf_ctx *ctx, void **p, size_t bytes);
+void pmf_dev_free(pmf_ctx *ctx, void *p, size_t bytes);
+int pmf_ensure_partial(pmf_ctx *ctx, size_t bytes);
+int pmf_ensure_scratch(pmf_ctx *ctx, size_t bytes);
+int pmf_ensure_pinned(pmf_ctx *ctx, size_t bytes);
+size_t pmf_array_elems(const pmf_ctx *ctx, int side, int array);  // device elements
+int pmf_require_array(pmf_ctx *ctx, int side, int array, const char *what);
+int pmf_alloc_array(pmf_ctx *ctx, int side, int array);  // no-op if present (zero-filled)
+
+// profiling brackets
+void pmf_prof_begin(pmf_ctx *ctx, int kernel);
+void pmf_prof_end(pmf_ctx *ctx);
+
+struct PmfProfScope {
+    pmf_ctx *ctx;
+    PmfProfScope(pmf_ctx *c, int kernel) : ctx(c) { pmf_prof_begin(c, kernel); }
+    ~PmfProfScope() { pmf_prof_end(ctx); }
+};
+
+static inline int pmf_lanes_per_row(int kpad) {
+    int kv = kpad / PMF_VEC;
+    int l = 1;
+    while (l < kv) l <<= 1;
+    return l;
+}

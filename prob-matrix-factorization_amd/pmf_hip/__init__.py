@@ -1,0 +1,131 @@
+"""ctypes binding of libpmf_hip.so (C-ABI declared in include/pmf_hip.h).
+
+The shared library is the product: there is no CPU fallback.  Importing this
+module never loads it; the first use does, and raises `PmfLibraryError` if the
+library has not been built (`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpmf_hip.so")
+
+F32, F64 = 0, 1
+USER, ITEM = 0, 1
+ARR_FACTOR, ARR_SHAPE, ARR_RATE, ARR_PRIOR_RATE, ARR_HYPER_RATE, ARR_COV, ARR_BIAS = range(7)
+KERNEL_NAMES = ("gamma_sweep", "gamma_final", "gauss_accum", "gauss_solve", "gauss_bias",
+                "eval", "predict", "topk")
+MAX_LABELS = 32
+
+
+class PmfLibraryError(RuntimeError):
+    """libpmf_hip.so is missing or does not export the declared ABI."""
+
+
+class PmfError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+_p = C.c_void_p
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); must list every function include/pmf_hip.h declares
+SIGNATURES = {
+    "pmf_abi_version": (C.c_int, []),
+    "pmf_last_error": (C.c_char_p, []),
+    "pmf_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pmf_ctx_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(_p)]),
+    "pmf_ctx_destroy": (C.c_int, [_p]),
+    "pmf_ctx_set_stream": (C.c_int, [_p, _p]),
+    "pmf_ctx_sync": (C.c_int, [_p]),
+    "pmf_ctx_device_bytes": (C.c_int, [_p, _i64p]),
+    "pmf_ctx_set_ratings": (C.c_int, [_p, C.c_int64, _i32p, _i32p, _f64p]),
+    "pmf_set_array": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
+    "pmf_get_array": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
+    "pmf_set_cov_identity": (C.c_int, [_p, C.c_int, C.c_double]),
+    "pmf_gamma_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
+    "pmf_ctx_kpad": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "pmf_gamma_accumulate": (C.c_int, [_p, C.c_int, _p]),
+    "pmf_gamma_finalize": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
+    "pmf_gauss_factor_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double]),
+    "pmf_gauss_bias_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double]),
+    "pmf_ctx_cov_stride": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "pmf_gauss_factor_accumulate": (C.c_int, [_p, C.c_int, _p]),
+    "pmf_gauss_factor_finalize": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double]),
+    "pmf_gauss_bias_accumulate": (C.c_int, [_p, C.c_int, _p]),
+    "pmf_gauss_bias_finalize": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double]),
+    "pmf_predict": (C.c_int, [_p, C.c_int64, _i32p, _i32p, C.c_int, C.c_double, _f64p]),
+    "pmf_eval_set": (C.c_int, [_p, C.c_int64, _i32p, _i32p, _f64p, _i32p, C.c_int]),
+    "pmf_eval_run": (C.c_int, [_p, C.c_int, C.c_double, _f64p, _f64p, _i64p]),
+    "pmf_topk_items": (C.c_int, [_p, C.c_int64, _i32p, C.c_int, C.c_int, _i32p, _f64p]),
+    "pmf_prof_enable": (C.c_int, [_p, C.c_int]),
+    "pmf_prof_reset": (C.c_int, [_p]),
+    "pmf_prof_get": (C.c_int, [_p, C.c_int, _f64p, _i64p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpmf_hip.so and bind every declared entry point (once)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PmfLibraryError(
+            f"{LIB_PATH} not found: the HIP engine has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` from the repository root. "
+            "There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # missing libamdhip64 etc.
+        raise PmfLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise PmfLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().pmf_last_error()
+        raise PmfError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().pmf_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def as_i32(ids, what="ids"):
+    """int ids -> contiguous int32 (the ABI's id type); refuses values that do not fit."""
+    a = np.asarray(ids)
+    if a.dtype != np.int32:
+        a64 = a.astype(np.int64, copy=False)
+        if a64.size and (a64.max() > np.iinfo(np.int32).max or a64.min() < np.iinfo(np.int32).min):
+            raise ValueError(f"{what}: values do not fit int32")
+        a = a64.astype(np.int32)
+    return np.ascontiguousarray(a)
+
+
+def as_f64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+from .engine import Context  # noqa: E402,F401

@@ -1,0 +1,212 @@
+"""`Context`: a thin Python owner of one `pmf_ctx` (one model instance on one GPU).
+
+Every method is a direct call through the C-ABI of include/pmf_hip.h; the
+class adds argument conversion (NumPy -> C pointers), error translation and
+lifetime management only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import (ARR_COV, F32, F64, ITEM, KERNEL_NAMES, MAX_LABELS, USER, PmfError, as_f64, as_i32,
+               check, load, ptr)
+
+
+class Context:
+    def __init__(self, n_users, n_items, n_factors, dtype="f32", device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(n_factors)
+        self.dtype = {"f32": F32, "f64": F64, F32: F32, F64: F64}[dtype]
+        self.np_dtype = np.float64 if self.dtype == F64 else np.float32
+        check(self._lib.pmf_ctx_create(int(device), self.n_users, self.n_items, self.K, self.dtype,
+                                       C.byref(self._h)), "pmf_ctx_create")
+        k = C.c_int(0)
+        check(self._lib.pmf_ctx_kpad(self._h, C.byref(k)), "pmf_ctx_kpad")
+        self.kpad = k.value
+        check(self._lib.pmf_ctx_cov_stride(self._h, C.byref(k)), "pmf_ctx_cov_stride")
+        self.cov_stride = k.value
+        self.nnz = 0
+
+    # ---- lifetime -------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pmf_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def rows(self, side):
+        return self.n_users if side == USER else self.n_items
+
+    def sync(self):
+        check(self._lib.pmf_ctx_sync(self._h), "pmf_ctx_sync")
+
+    def set_stream(self, hip_stream):
+        check(self._lib.pmf_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)), "pmf_ctx_set_stream")
+
+    def device_bytes(self):
+        n = C.c_int64(0)
+        check(self._lib.pmf_ctx_device_bytes(self._h, C.byref(n)), "pmf_ctx_device_bytes")
+        return n.value
+
+    # ---- data -----------------------------------------------------------
+    def set_ratings(self, user_ids, item_ids, ratings):
+        u, i, x = as_i32(user_ids, "user_ids"), as_i32(item_ids, "item_ids"), as_f64(ratings)
+        if not (len(u) == len(i) == len(x)):
+            raise ValueError("user_ids, item_ids and ratings must have the same length")
+        check(self._lib.pmf_ctx_set_ratings(self._h, len(u), ptr(u, C.c_int32), ptr(i, C.c_int32),
+                                            ptr(x, C.c_double)), "pmf_ctx_set_ratings")
+        self.nnz = len(u)
+
+    def _host_shape(self, side, array):
+        r = self.rows(side)
+        if array in (0, 1, 2):
+            return (r, self.K)
+        if array == ARR_COV:
+            return (r, self.K, self.K)
+        return (r,)
+
+    def set_array(self, side, array, host):
+        a = as_f64(host)
+        if a.shape != self._host_shape(side, array):
+            raise ValueError(f"array {array} of side {side}: expected shape "
+                             f"{self._host_shape(side, array)}, got {a.shape}")
+        check(self._lib.pmf_set_array(self._h, side, array, ptr(a, C.c_double)), "pmf_set_array")
+
+    def get_array(self, side, array):
+        out = np.empty(self._host_shape(side, array), dtype=np.float64)
+        check(self._lib.pmf_get_array(self._h, side, array, ptr(out, C.c_double)), "pmf_get_array")
+        return out
+
+    def set_cov_identity(self, side, scale=1.0):
+        check(self._lib.pmf_set_cov_identity(self._h, side, float(scale)), "pmf_set_cov_identity")
+
+    # ---- Poisson / HPF --------------------------------------------------
+    def gamma_sweep(self, side, shape_prior, rate_prior, hierarchical=False, hyper_shape=0.0,
+                    hyper_rate_prior=0.0):
+        check(self._lib.pmf_gamma_sweep(self._h, side, float(shape_prior), float(rate_prior),
+                                        int(bool(hierarchical)), float(hyper_shape),
+                                        float(hyper_rate_prior)), "pmf_gamma_sweep")
+
+    def gamma_accumulate(self, side, stats_ptr):
+        check(self._lib.pmf_gamma_accumulate(self._h, side, C.c_void_p(stats_ptr)), "pmf_gamma_accumulate")
+
+    def gamma_finalize(self, side, stats_ptr, shape_prior, rate_prior, hierarchical=False,
+                       hyper_shape=0.0, hyper_rate_prior=0.0):
+        check(self._lib.pmf_gamma_finalize(self._h, side, C.c_void_p(stats_ptr), float(shape_prior),
+                                           float(rate_prior), int(bool(hierarchical)),
+                                           float(hyper_shape), float(hyper_rate_prior)),
+              "pmf_gamma_finalize")
+
+    # ---- Gaussian -------------------------------------------------------
+    def gauss_factor_sweep(self, side, sigma2, eta2):
+        check(self._lib.pmf_gauss_factor_sweep(self._h, side, float(sigma2), float(eta2)),
+              "pmf_gauss_factor_sweep")
+
+    def gauss_bias_sweep(self, side, sigma2, eta_bias2):
+        check(self._lib.pmf_gauss_bias_sweep(self._h, side, float(sigma2), float(eta_bias2)),
+              "pmf_gauss_bias_sweep")
+
+    def gauss_factor_accumulate(self, side, stats_ptr):
+        check(self._lib.pmf_gauss_factor_accumulate(self._h, side, C.c_void_p(stats_ptr)),
+              "pmf_gauss_factor_accumulate")
+
+    def gauss_factor_finalize(self, side, stats_ptr, sigma2, eta2):
+        check(self._lib.pmf_gauss_factor_finalize(self._h, side, C.c_void_p(stats_ptr), float(sigma2),
+                                                  float(eta2)), "pmf_gauss_factor_finalize")
+
+    def gauss_bias_accumulate(self, side, stats_ptr):
+        check(self._lib.pmf_gauss_bias_accumulate(self._h, side, C.c_void_p(stats_ptr)),
+              "pmf_gauss_bias_accumulate")
+
+    def gauss_bias_finalize(self, side, stats_ptr, sigma2, eta_bias2):
+        check(self._lib.pmf_gauss_bias_finalize(self._h, side, C.c_void_p(stats_ptr), float(sigma2),
+                                                float(eta_bias2)), "pmf_gauss_bias_finalize")
+
+    # ---- predict / evaluate --------------------------------------------
+    @staticmethod
+    def _clip_ids(ids):
+        """Ids beyond int32 cannot be valid rows; map them to an id that is
+        out of range for every table so they predict 0 like the reference."""
+        a = np.asarray(ids, dtype=np.int64)
+        big = np.iinfo(np.int32).max
+        return np.ascontiguousarray(np.where((a > big) | (a < 0), big, a).astype(np.int32))
+
+    def predict(self, user_ids, item_ids, use_bias=False, offset=0.0):
+        u, i = self._clip_ids(user_ids), self._clip_ids(item_ids)
+        if len(u) != len(i):
+            raise ValueError("user_ids and item_ids must have the same length")
+        out = np.zeros(len(u), dtype=np.float64)
+        if len(u):
+            check(self._lib.pmf_predict(self._h, len(u), ptr(u, C.c_int32), ptr(i, C.c_int32),
+                                        int(bool(use_bias)), float(offset), ptr(out, C.c_double)),
+                  "pmf_predict")
+        return out
+
+    def eval_set(self, user_ids, item_ids, y_true):
+        """Store a validation set on the device.  Returns False (and stores
+        nothing) when y_true has more than MAX_LABELS distinct values -- the
+        caller then evaluates through `predict`."""
+        y = as_f64(y_true)
+        labels, inverse = np.unique(y, return_inverse=True)
+        if len(labels) > MAX_LABELS or len(y) == 0:
+            return False
+        u, i = self._clip_ids(user_ids), self._clip_ids(item_ids)
+        lab = np.ascontiguousarray(inverse.astype(np.int32))
+        check(self._lib.pmf_eval_set(self._h, len(y), ptr(u, C.c_int32), ptr(i, C.c_int32),
+                                     ptr(y, C.c_double), ptr(lab, C.c_int32), len(labels)),
+              "pmf_eval_set")
+        self._eval_n, self._eval_labels = len(y), len(labels)
+        return True
+
+    def eval_run(self, use_bias=False, offset=0.0):
+        """(rmse, macro_mae) over the stored validation set (metrics.py:6-10, :37-51)."""
+        sse = C.c_double(0.0)
+        abs_l = np.zeros(MAX_LABELS, dtype=np.float64)
+        cnt_l = np.zeros(MAX_LABELS, dtype=np.int64)
+        check(self._lib.pmf_eval_run(self._h, int(bool(use_bias)), float(offset), C.byref(sse),
+                                     ptr(abs_l, C.c_double), ptr(cnt_l, C.c_int64)), "pmf_eval_run")
+        L = self._eval_labels
+        rmse = float(np.sqrt(sse.value / self._eval_n))
+        macro = float(np.mean(abs_l[:L] / cnt_l[:L]))
+        return rmse, macro
+
+    def topk_items(self, user_ids, k, use_bias=False):
+        u = as_i32(user_ids, "user_ids")
+        items = np.empty((len(u), k), dtype=np.int32)
+        scores = np.empty((len(u), k), dtype=np.float64)
+        check(self._lib.pmf_topk_items(self._h, len(u), ptr(u, C.c_int32), int(k), int(bool(use_bias)),
+                                       ptr(items, C.c_int32), ptr(scores, C.c_double)), "pmf_topk_items")
+        return items, scores
+
+    # ---- profiling ------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(self._lib.pmf_prof_enable(self._h, int(bool(on))), "pmf_prof_enable")
+
+    def prof_reset(self):
+        check(self._lib.pmf_prof_reset(self._h), "pmf_prof_reset")
+
+    def prof_get(self):
+        """{kernel_name: (total_ms, launches)} since the last reset."""
+        out = {}
+        for k, name in enumerate(KERNEL_NAMES):
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            check(self._lib.pmf_prof_get(self._h, k, C.byref(ms), C.byref(n)), "pmf_prof_get")
+            out[name] = (ms.value, n.value)
+        return out
+
+
+__all__ = ["Context", "PmfError", "USER", "ITEM"]

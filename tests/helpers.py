@@ -1,0 +1,43 @@
+"""Shared helpers for the GPU parity tests."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return d, json.loads(str(d["meta"]))
+
+
+def frames(d):
+    train = pd.DataFrame({"u": d["train_u"], "i": d["train_i"], "rating": d["train_rating"]})
+    val = pd.DataFrame({"u": d["val_u"], "i": d["val_i"], "rating": d["val_rating"]})
+    return train, val
+
+
+def skewed_problem(seed, U, I, N, rating_kind="count"):
+    """Power-law rows (SURVEY.md section 8d generator): heavy head rows exercise
+    the split-row path, ids never drawn give empty rows."""
+    rng = np.random.default_rng(seed)
+    u = rng.permutation(U)[np.floor(U * rng.random(N) ** 2.0).astype(np.int64)]
+    i = rng.permutation(I)[np.floor(I * rng.random(N) ** 3.0).astype(np.int64)]
+    u[0], i[0] = U - 1, I - 1
+    r = rng.choice(6, size=N, p=[0.032, 0.006, 0.012, 0.036, 0.142, 0.772]).astype(np.float64)
+    if rating_kind == "count":
+        r += 1.0
+    elif rating_kind == "centered":
+        r -= r.mean()
+    return u, i, r
+
+
+def rel_err(a, b, floor=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + floor))) if a.size else 0.0
+
+
+def max_abs(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0

@@ -187,6 +187,9 @@ static void free_index(pmf_ctx *ctx) {
         ix.d_ptr = nullptr;
         ix.d_other = nullptr;
         ix.d_val = nullptr;
+        pmf_dev_free(ctx, ix.d_nonempty, (size_t)ix.n_nonempty * sizeof(int32_t));
+        ix.d_nonempty = nullptr;
+        ix.n_nonempty = 0;
         ix.h_ptr.clear();
         free_tasks(ctx, ix.gamma_tasks);
         free_tasks(ctx, ix.gauss_tasks);
@@ -376,6 +379,13 @@ extern "C" int pmf_ctx_set_ratings(pmf_ctx *ctx, int64_t nnz, const int32_t *use
             PMF_HIP_CHECK(hipMemcpy(ix.d_other, other.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
             PMF_HIP_CHECK(hipMemcpy(ix.d_val, val.data(), (size_t)nnz * ctx->elem, hipMemcpyHostToDevice));
         }
+        std::vector<int32_t> nonempty;
+        for (int64_t r = 0; r < rows; ++r)
+            if (ix.h_ptr[(size_t)r + 1] > ix.h_ptr[(size_t)r]) nonempty.push_back((int32_t)r);
+        ix.n_nonempty = (int64_t)nonempty.size();
+        if ((rc = pmf_dev_alloc(ctx, (void **)&ix.d_nonempty, nonempty.size() * sizeof(int32_t)))) return rc;
+        if (!nonempty.empty())
+            PMF_HIP_CHECK(hipMemcpy(ix.d_nonempty, nonempty.data(), nonempty.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         if ((rc = upload_tasks(ctx, ix.h_ptr, rows, PMF_GAMMA_CHUNK, true, ix.gamma_tasks))) return rc;
         if ((rc = upload_tasks(ctx, ix.h_ptr, rows, PMF_GAUSS_CHUNK, false, ix.gauss_tasks))) return rc;
         if ((rc = upload_tasks(ctx, ix.h_ptr, rows, PMF_GAMMA_CHUNK, false, ix.bias_tasks))) return rc;

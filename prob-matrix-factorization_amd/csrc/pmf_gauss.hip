@@ -1,9 +1,807 @@
-// placeholder, replaced below
+// Gaussian MF half-sweep kernels (rows a8, a9 of SURVEY.md section 8).
+//
+// A factor half-sweep is two phases:
+//   accumulate : per row r, S = sum_j (COV_other[o_j] + m_j m_j^T) (packed lower
+//                triangle) and w = sum_j m_j * resid_j.  Pure streaming: every
+//                rating gathers one packed covariance row (K(K+1)/2 values) and
+//                one mean row.  One wavefront per task (run of <= PMF_GAUSS_CHUNK
+//                ratings of one row), sums in registers, written once.  The
+//                sums go IN PLACE into COV_side[r] / FACTOR_side[r] (nobody
+//                gathers this side during its own sweep), so no row-sized
+//                scratch is needed at 1M+ rows.
+//   solve      : per non-empty row, COV[r] = inv(I/eta2 + S/sigma2) and
+//                FACTOR[r] = COV[r] w / sigma2, one wavefront per row with the
+//                whole K x K matrix in registers (lane = column).
+// K = 64 / fp32 (the benchmark configuration) has a dedicated accumulate kernel
+// that forms sum_j m_j m_j^T on the matrix cores (v_mfma_f32_32x32x2_f32: exact
+// fp32 FMA chains) while the VALU only adds the gathered covariance rows.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
 #include "pmf_device.h"
-extern "C" int pmf_gauss_factor_sweep(pmf_ctx *, int, double, double) { pmf_set_error("not built yet"); return PMF_EINVAL; }
-extern "C" int pmf_gauss_bias_sweep(pmf_ctx *, int, double, double) { pmf_set_error("not built yet"); return PMF_EINVAL; }
-extern "C" int pmf_gauss_factor_accumulate(pmf_ctx *, int, void *) { pmf_set_error("not built yet"); return PMF_EINVAL; }
-extern "C" int pmf_gauss_factor_finalize(pmf_ctx *, int, const void *, double, double) { pmf_set_error("not built yet"); return PMF_EINVAL; }
-extern "C" int pmf_gauss_bias_accumulate(pmf_ctx *, int, void *) { pmf_set_error("not built yet"); return PMF_EINVAL; }
-extern "C" int pmf_gauss_bias_finalize(pmf_ctx *, int, const void *, double, double) { pmf_set_error("not built yet"); return PMF_EINVAL; }
-extern "C" int pmf_topk_items(pmf_ctx *, int64_t, const int32_t *, int, int, int32_t *, double *) { pmf_set_error("not built yet"); return PMF_EINVAL; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T>
+struct GaussParams {
+    const PmfTask *tasks;
+    int64_t n_tasks;
+    const PmfSplitRow *split;
+    const int32_t *other;
+    const T *val;
+    const T *factor_other;
+    const T *cov_other;
+    const T *bias_self;   // null when the model has no biases
+    const T *bias_other;
+    T *partial;           // [n_slots][cov_stride + kpad]
+    // destination of a complete row's raw sums
+    T *dst_s;
+    int64_t dst_s_stride;
+    T *dst_w;
+    int64_t dst_w_stride;
+    int K, kpad, kp, cov_stride;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wavefront execute in order; this only stops the
+    // compiler from moving LDS accesses across the point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ PmfTask load_task_uniform(const PmfTask *tasks, int64_t id) {
+    PmfTask t = tasks[id];
+    PmfTask r;
+    r.row = rfl(t.row);
+    r.len = rfl(t.len);
+    r.slot = rfl(t.slot);
+    r.pad = 0;
+    unsigned lo = (unsigned)rfl((int)(t.start & 0xFFFFFFFFll)), hi = (unsigned)rfl((int)(t.start >> 32));
+    r.start = (int64_t)(((unsigned long long)hi << 32) | lo);
+    return r;
+}
+
+// packed index p -> (row, col) of the lower triangle
+__device__ __forceinline__ void tri_rc(int p, int &r, int &c) {
+    r = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= p) ++r;
+    while (r * (r + 1) / 2 > p) --r;
+    c = p - r * (r + 1) / 2;
+}
+
+// ---------------------------------------------------------------------------
+// accumulate, generic (any K <= 256, fp32 / fp64)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T> p) {
+    constexpr int EPL = 8;  // packed entries per lane per pass
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
+    if (task_id >= p.n_tasks) return;
+    const PmfTask t = load_task_uniform(p.tasks, task_id);
+    T *mrow = reinterpret_cast<T *>(smem_raw) + wave * p.kpad;
+    const int32_t *col = p.other + t.start;
+    const T *val = p.val + t.start;
+    const T b_self = p.bias_self ? p.bias_self[t.row] : (T)0;
+    T *out_s, *out_w;
+    if (t.slot >= 0) {
+        out_s = p.partial + (int64_t)t.slot * (p.cov_stride + p.kpad);
+        out_w = out_s + p.cov_stride;
+    } else {
+        out_s = p.dst_s + (int64_t)t.row * p.dst_s_stride;
+        out_w = p.dst_w + (int64_t)t.row * p.dst_w_stride;
+    }
+    T wacc[4] = {(T)0, (T)0, (T)0, (T)0};
+    for (int p0 = 0; p0 < p.cov_stride; p0 += 64 * EPL) {
+        int rr[EPL], cc[EPL];
+        T acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int pi = p0 + e * 64 + lane;
+            rr[e] = 0;
+            cc[e] = 0;
+            if (pi < p.kp) tri_rc(pi, rr[e], cc[e]);
+            acc[e] = (T)0;
+        }
+        for (int j = 0; j < t.len; ++j) {
+            const int o = col[j];
+            for (int k = lane; k < p.kpad; k += 64) mrow[k] = p.factor_other[(int64_t)o * p.kpad + k];
+            wave_lds_fence();
+            if (p0 == 0) {
+                const T resid = val[j] - b_self - (p.bias_other ? p.bias_other[o] : (T)0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = lane + 64 * e;
+                    if (k < p.K) wacc[e] += mrow[k] * resid;
+                }
+            }
+            const T *vrow = p.cov_other + (int64_t)o * p.cov_stride;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int pi = p0 + e * 64 + lane;
+                if (pi < p.kp) acc[e] += fma(mrow[rr[e]], mrow[cc[e]], vrow[pi]);
+            }
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int pi = p0 + e * 64 + lane;
+            if (pi < p.cov_stride) out_s[pi] = pi < p.kp ? acc[e] : (T)0;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = lane + 64 * e;
+        if (k < p.kpad) out_w[k] = k < p.K ? wacc[e] : (T)0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// accumulate, K = 64 fp32: covariance rows on the VALU, m m^T on the MFMA pipe
+// ---------------------------------------------------------------------------
+// Packed row length 2080 floats = 520 16-byte chunks: chunk q = lane + 64 t,
+// t = 0..8 (t = 8 only lanes 0..7).  Two ratings per step feed one
+// v_mfma_f32_32x32x2_f32 (k = 2): lanes 0-31 carry rating j, lanes 32-63 rating
+// j+1; the three lower 32x32 blocks of the 64x64 outer-product sum live in 48
+// accumulator registers and are folded into the packed image through LDS once
+// per task.
+#define G64_KP 2080
+#define G64_CHUNKS 520
+#define G64_T 9
+
+__global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<float> p) {
+    __shared__ __align__(16) float lds[4][G64_KP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
+    if (task_id >= p.n_tasks) return;
+    const PmfTask t = load_task_uniform(p.tasks, task_id);
+    const int h = lane >> 5, c = lane & 31;
+    const int32_t *col = p.other + t.start;
+    const float *val = p.val + t.start;
+    const float b_self = p.bias_self ? p.bias_self[t.row] : 0.f;
+
+    f32x16 d00, d10, d11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        d00[r] = 0.f;
+        d10[r] = 0.f;
+        d11[r] = 0.f;
+    }
+    float4 acc[G64_T];
+#pragma unroll
+    for (int s = 0; s < G64_T; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wlo = 0.f, whi = 0.f;
+
+    for (int j = 0; j < t.len; j += 2) {
+        const bool two = (j + 1) < t.len;
+        const int o0 = col[j];
+        const int o1 = two ? col[j + 1] : o0;
+        const int oh = h ? o1 : o0;
+        const bool live = (h == 0) || two;
+        const float *mrow = p.factor_other + (int64_t)oh * 64;
+        float mlo = mrow[c], mhi = mrow[32 + c];
+        const float xh = val[j + (live ? h : 0)];
+        const float resid = xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f);
+        if (!live) {
+            mlo = 0.f;
+            mhi = 0.f;
+        }
+        wlo = fmaf(mlo, resid, wlo);
+        whi = fmaf(mhi, resid, whi);
+        const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * G64_KP);
+        const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * G64_KP);
+        float4 a[G64_T], b[G64_T];
+#pragma unroll
+        for (int s = 0; s < G64_T; ++s) {
+            const int q = lane + 64 * s;
+            a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < G64_CHUNKS) {
+                a[s] = v0[q];
+                if (two) b[s] = v1[q];
+            }
+        }
+        d00 = __builtin_amdgcn_mfma_f32_32x32x2f32(mlo, mlo, d00, 0, 0, 0);
+        d10 = __builtin_amdgcn_mfma_f32_32x32x2f32(mhi, mlo, d10, 0, 0, 0);
+        d11 = __builtin_amdgcn_mfma_f32_32x32x2f32(mhi, mhi, d11, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < G64_T; ++s) {
+            acc[s].x += a[s].x + b[s].x;
+            acc[s].y += a[s].y + b[s].y;
+            acc[s].z += a[s].z + b[s].z;
+            acc[s].w += a[s].w + b[s].w;
+        }
+    }
+
+    // fold the outer-product blocks into the packed image via LDS
+    float *img = lds[wave];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of 32x32 MFMA
+        const int R1 = 32 + row;
+        if (c <= row) img[row * (row + 1) / 2 + c] = d00[r];
+        img[R1 * (R1 + 1) / 2 + c] = d10[r];
+        if (c <= row) img[R1 * (R1 + 1) / 2 + 32 + c] = d11[r];
+    }
+    wave_lds_fence();
+    float *out_s, *out_w;
+    if (t.slot >= 0) {
+        out_s = p.partial + (int64_t)t.slot * (G64_KP + 64);
+        out_w = out_s + G64_KP;
+    } else {
+        out_s = p.dst_s + (int64_t)t.row * p.dst_s_stride;
+        out_w = p.dst_w + (int64_t)t.row * p.dst_w_stride;
+    }
+#pragma unroll
+    for (int s = 0; s < G64_T; ++s) {
+        const int q = lane + 64 * s;
+        if (q < G64_CHUNKS) {
+            const float4 m = reinterpret_cast<const float4 *>(img)[q];
+            float4 o = acc[s];
+            o.x += m.x;
+            o.y += m.y;
+            o.z += m.z;
+            o.w += m.w;
+            reinterpret_cast<float4 *>(out_s)[q] = o;
+        }
+    }
+    wlo += __shfl_xor(wlo, 32, 64);
+    whi += __shfl_xor(whi, 32, 64);
+    if (h == 0) {
+        out_w[c] = wlo;
+        out_w[32 + c] = whi;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// combine the partial slots of split rows (slot order => deterministic)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_combine_kernel(GaussParams<T> p) {
+    const PmfSplitRow sr = p.split[blockIdx.x];
+    const int width = p.cov_stride + p.kpad;
+    T *out_s = p.dst_s + (int64_t)sr.row * p.dst_s_stride;
+    T *out_w = p.dst_w + (int64_t)sr.row * p.dst_w_stride;
+    for (int e = threadIdx.x; e < width; e += 256) {
+        const T *src = p.partial + (int64_t)sr.first_slot * width + e;
+        T s = (T)0;
+        for (int k = 0; k < sr.n_slots; ++k) s += src[(int64_t)k * width];
+        if (e < p.cov_stride) out_s[e] = s;
+        else out_w[e - p.cov_stride] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// solve: V = inv(I/eta2 + S/sigma2), m = V w / sigma2
+// ---------------------------------------------------------------------------
+template <typename T>
+struct SolveParams {
+    const int32_t *rows;  // list of rows to solve, or null = every row (skip rows with S == 0)
+    int64_t n;
+    const T *src_s;
+    int64_t src_s_stride;
+    const T *src_w;
+    int64_t src_w_stride;
+    T *cov;
+    T *factor;
+    T inv_sigma2, inv_eta2;
+    int K, kpad, cov_stride;
+};
+
+__device__ __forceinline__ float readlane_dyn(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ double readlane_dyn(double x, int lane) {
+    long long q = __builtin_bit_cast(long long, x);
+    int lo = __builtin_amdgcn_readlane((int)(q & 0xFFFFFFFFll), lane);
+    int hi = __builtin_amdgcn_readlane((int)(q >> 32), lane);
+    q = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, q);
+}
+
+// One wavefront per row, lane j = column j, B[i] = row (i + step) mod KR.
+// Symmetric sweep on the Jacobi-scaled matrix (unit diagonal => pivots in
+// (0, 1], which keeps the column update fma(-s, 1 - 1/d, s) = s/d free of
+// cancellation).  The pivot row is always register 0 because every update
+// writes row i into register i-1; after KR steps the rows are back in place
+// and B = -inverse.
+template <typename T, int KR>
+__global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
+    if (idx >= p.n) return;
+    const int row = p.rows ? rfl(p.rows[idx]) : (int)idx;
+    const T *S = p.src_s + (int64_t)row * p.src_s_stride;
+    if (!p.rows && S[0] == (T)0) return;  // no rating anywhere for this row
+    T *img = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * p.cov_stride;
+    for (int q = lane * PMF_VEC; q < p.cov_stride; q += 64 * PMF_VEC) store4(img + q, load4(S + q));
+    wave_lds_fence();
+    const int K = p.K, j = lane;
+    T B[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        T s = (T)0;
+        if (i < K && j < K) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            s = img[hi * (hi + 1) / 2 + lo] * p.inv_sigma2;
+        }
+        if (i == j) s += (i < K) ? p.inv_eta2 : (T)1;
+        B[i] = s;
+    }
+    // Jacobi scaling g_j = 1/sqrt(P_jj)
+    T diag = (T)1;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const T dii = readlane_dyn(B[i], i);
+        if (j == i) diag = dii;
+    }
+    const T g = (T)1 / sqrt(diag);
+#pragma unroll
+    for (int i = 0; i < KR; ++i) B[i] = B[i] * g * readlane_dyn(g, i);
+
+    for (int k = 0; k < KR; ++k) {
+        const T v = B[0];
+        const T pinv = (T)1 / readlane_dyn(v, k);
+        const T u = v * pinv;
+        const T uc = (j == k) ? ((T)1 - pinv) : u;
+#pragma unroll
+        for (int i = 1; i < KR; ++i) {
+            const T s = readlane_dyn(B[i], k);
+            B[i - 1] = fma(-s, uc, B[i]);
+        }
+        B[KR - 1] = (j == k) ? -pinv : u;
+    }
+    // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
+    const T wj = (j < K) ? p.src_w[(int64_t)row * p.src_w_stride + j] : (T)0;
+    T mj = (T)0;
+    T *vout = p.cov + (int64_t)row * p.cov_stride;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const T vij = -B[i] * g * readlane_dyn(g, i);
+        mj = fma(vij, readlane_dyn(wj, i), mj);
+        if (i < K && j <= i) vout[i * (i + 1) / 2 + j] = vij;
+    }
+    if (j < p.kpad) p.factor[(int64_t)row * p.kpad + j] = (j < K) ? mj * p.inv_sigma2 : (T)0;
+}
+
+// Generic solve for 64 < K <= 128: one block per row, full matrix in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_solve_lds_kernel(SolveParams<T> p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int64_t idx = blockIdx.x;
+    const int row = p.rows ? p.rows[idx] : (int)idx;
+    const T *S = p.src_s + (int64_t)row * p.src_s_stride;
+    if (!p.rows && S[0] == (T)0) return;
+    const int K = p.K, ld = K + 1;
+    T *A = reinterpret_cast<T *>(smem_raw);  // [K][ld]
+    T *g = A + K * ld;                       // [K] scaling
+    T *prow = g + K;                         // [K] scaled pivot row
+    T *pcol = prow + K;                      // [K] pivot column
+    const int tid = threadIdx.x;
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e / K, j = e % K;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        T s = S[hi * (hi + 1) / 2 + lo] * p.inv_sigma2;
+        if (i == j) s += p.inv_eta2;
+        A[i * ld + j] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < K; i += 256) g[i] = (T)1 / sqrt(A[i * ld + i]);
+    __syncthreads();
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e / K, j = e % K;
+        A[i * ld + j] *= g[i] * g[j];
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const T pinv = (T)1 / A[k * ld + k];
+        __syncthreads();
+        for (int i = tid; i < K; i += 256) {
+            prow[i] = A[k * ld + i] * pinv;
+            pcol[i] = A[i * ld + k];
+        }
+        __syncthreads();
+        for (int e = tid; e < K * K; e += 256) {
+            const int i = e / K, j = e % K;
+            T x;
+            if (i == k) x = (j == k) ? -pinv : prow[j];
+            else if (j == k) x = pcol[i] * pinv;
+            else x = fma(-pcol[i], prow[j], A[i * ld + j]);
+            A[i * ld + j] = x;
+        }
+        __syncthreads();
+    }
+    // V = -g g A ; m = inv_sigma2 V w
+    T *vout = p.cov + (int64_t)row * p.cov_stride;
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e / K, j = e % K;
+        const T v = -A[i * ld + j] * g[i] * g[j];
+        A[i * ld + j] = v;
+        if (j <= i) vout[i * (i + 1) / 2 + j] = v;
+    }
+    for (int i = tid; i < K; i += 256) prow[i] = p.src_w[(int64_t)row * p.src_w_stride + i];
+    __syncthreads();
+    for (int i = tid; i < p.kpad; i += 256) {
+        T m = (T)0;
+        if (i < K)
+            for (int jj = 0; jj < K; ++jj) m = fma(A[i * ld + jj], prow[jj], m);
+        p.factor[(int64_t)row * p.kpad + i] = m * p.inv_sigma2;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bias half-sweep (lane group per task, same decomposition as the gamma sweep)
+// ---------------------------------------------------------------------------
+template <typename T>
+struct BiasParams {
+    const PmfTask *tasks;
+    int64_t n_tasks;
+    const PmfSplitRow *split;
+    const int32_t *other;
+    const T *val;
+    const T *factor_self;
+    const T *factor_other;
+    T *bias_self;
+    const T *bias_other;
+    T *partial;  // [n_slots]
+    T *stats;    // [rows][2] (residual sum, count), STATS mode
+    T inv_sigma2, inv_eta_bias2;
+    int kpad;
+    int64_t rows;
+};
+
+template <typename T>
+__device__ __forceinline__ T bias_from_sum(const BiasParams<T> &p, T sum, T count) {
+    // gaussian_mf_cavi_bias.py:222-230: var = 1/(1/eta_b2 + n/sigma2); b = var/sigma2 * sum
+    const T var = (T)1 / (p.inv_eta_bias2 + count * p.inv_sigma2);
+    return (var * p.inv_sigma2) * sum;
+}
+
+template <typename T, int LPR, bool STATS>
+__global__ __launch_bounds__(256) void gauss_bias_kernel(BiasParams<T> p) {
+    constexpr int G = 256 / LPR;
+    constexpr int UN = LPR < 4 ? LPR : 4;
+    const int c = threadIdx.x % LPR;
+    const int64_t task_id = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
+    if (task_id >= p.n_tasks) return;
+    const PmfTask t = p.tasks[task_id];
+    const int koff = c * PMF_VEC;
+    const bool active = koff < p.kpad;
+    const Vec4<T> self = active ? load4(p.factor_self + (int64_t)t.row * p.kpad + koff) : zero4<T>();
+    const int32_t *col = p.other + t.start;
+    const T *val = p.val + t.start;
+    T sum = (T)0;
+    for (int base = 0; base < t.len; base += LPR) {
+        const int n = min(LPR, t.len - base);
+        int my_o = 0;
+        T my_r = (T)0;
+        if (c < n) {
+            my_o = col[base + c];
+            my_r = val[base + c] - p.bias_other[my_o];
+        }
+        for (int tt = 0; tt < n; tt += UN) {
+            int o[UN];
+            T rv[UN];
+            Vec4<T> b[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                o[q] = __shfl(my_o, tt + q, LPR);
+                rv[q] = __shfl(my_r, tt + q, LPR);
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+                b[q] = active ? load4(p.factor_other + (int64_t)o[q] * p.kpad + koff) : zero4<T>();
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                if (tt + q < n) {
+                    T d = b[q].v[0] * self.v[0];
+                    d = fma(b[q].v[1], self.v[1], d);
+                    d = fma(b[q].v[2], self.v[2], d);
+                    d = fma(b[q].v[3], self.v[3], d);
+                    d = group_sum<LPR>(d);
+                    sum += rv[q] - d;
+                }
+            }
+        }
+    }
+    if (c != 0) return;
+    if (t.slot >= 0) {
+        p.partial[t.slot] = sum;
+    } else if (STATS) {
+        p.stats[(int64_t)t.row * 2] = sum;
+        p.stats[(int64_t)t.row * 2 + 1] = (T)t.len;
+    } else {
+        p.bias_self[t.row] = bias_from_sum(p, sum, (T)t.len);
+    }
+}
+
+template <typename T, bool STATS>
+__global__ void gauss_bias_split_kernel(BiasParams<T> p, int64_t n_split, const int64_t *ptr) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_split) return;
+    const PmfSplitRow sr = p.split[s];
+    T sum = (T)0;
+    for (int k = 0; k < sr.n_slots; ++k) sum += p.partial[sr.first_slot + k];
+    const T cnt = (T)(ptr[sr.row + 1] - ptr[sr.row]);
+    if (STATS) {
+        p.stats[(int64_t)sr.row * 2] = sum;
+        p.stats[(int64_t)sr.row * 2 + 1] = cnt;
+    } else {
+        p.bias_self[sr.row] = bias_from_sum(p, sum, cnt);
+    }
+}
+
+template <typename T>
+__global__ void gauss_bias_finalize_all_kernel(BiasParams<T> p) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.rows) return;
+    const T cnt = p.stats[r * 2 + 1];
+    if (cnt > (T)0) p.bias_self[r] = bias_from_sum(p, p.stats[r * 2], cnt);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+#define GAUSS_PROLOGUE(fn)                                                                              \
+    PMF_REQUIRE(ctx != nullptr, PMF_EINVAL, fn ": null context");                                       \
+    PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, fn ": bad side %d", side);  \
+    PMF_REQUIRE(ctx->K <= 128, PMF_ERANGE, fn ": the Gaussian path supports n_factors <= 128 (got %d)", ctx->K); \
+    PMF_HIP_CHECK(hipSetDevice(ctx->device));
+
+static bool use_bias(const pmf_ctx *ctx) {
+    return ctx->arr[0][PMF_ARR_BIAS] != nullptr && ctx->arr[1][PMF_ARR_BIAS] != nullptr;
+}
+
+// mode 0: fused (sums in place, then solve)   mode 1: accumulate into stats
+template <typename T>
+static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats) {
+    const int other = 1 - side;
+    const PmfSideIndex &ix = ctx->index[side];
+    const PmfTaskList &tl = ix.gauss_tasks;
+    int rc;
+    PMF_REQUIRE(ix.d_ptr, PMF_EINVAL, "pmf_gauss_factor_sweep: ratings have not been set");
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gauss_factor_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_COV, "pmf_gauss_factor_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, other, PMF_ARR_FACTOR, "pmf_gauss_factor_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, other, PMF_ARR_COV, "pmf_gauss_factor_sweep"))) return rc;
+    const int width = ctx->cov_stride + ctx->kpad;
+    if (tl.n_slots > 0)
+        if ((rc = pmf_ensure_partial(ctx, (size_t)tl.n_slots * width * sizeof(T)))) return rc;
+    GaussParams<T> p;
+    p.tasks = tl.d_tasks;
+    p.n_tasks = tl.n_tasks;
+    p.split = tl.d_split;
+    p.other = ix.d_other;
+    p.val = (const T *)ix.d_val;
+    p.factor_other = (const T *)ctx->arr[other][PMF_ARR_FACTOR];
+    p.cov_other = (const T *)ctx->arr[other][PMF_ARR_COV];
+    const bool bias = use_bias(ctx);
+    p.bias_self = bias ? (const T *)ctx->arr[side][PMF_ARR_BIAS] : nullptr;
+    p.bias_other = bias ? (const T *)ctx->arr[other][PMF_ARR_BIAS] : nullptr;
+    p.partial = (T *)ctx->d_partial;
+    if (stats) {
+        PMF_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)ctx->rows[side] * width * sizeof(T), ctx->stream));
+        p.dst_s = (T *)stats;
+        p.dst_s_stride = width;
+        p.dst_w = (T *)stats + ctx->cov_stride;
+        p.dst_w_stride = width;
+    } else {
+        p.dst_s = (T *)ctx->arr[side][PMF_ARR_COV];
+        p.dst_s_stride = ctx->cov_stride;
+        p.dst_w = (T *)ctx->arr[side][PMF_ARR_FACTOR];
+        p.dst_w_stride = ctx->kpad;
+    }
+    p.K = ctx->K;
+    p.kpad = ctx->kpad;
+    p.kp = ctx->kp;
+    p.cov_stride = ctx->cov_stride;
+    if (tl.n_tasks > 0) {
+        PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_ACCUM);
+        dim3 grid((unsigned)((tl.n_tasks + 3) / 4));
+        bool fast = false;
+        if constexpr (std::is_same<T, float>::value) {
+            if (ctx->K == 64 && !getenv("PMF_GAUSS_GENERIC")) {
+                fast = true;
+                hipLaunchKernelGGL(gauss_accum_k64_kernel, grid, dim3(256), 0, ctx->stream, p);
+            }
+        }
+        if (!fast)
+            hipLaunchKernelGGL((gauss_accum_generic_kernel<T>), grid, dim3(256),
+                               (size_t)4 * ctx->kpad * sizeof(T), ctx->stream, p);
+    }
+    if (tl.n_split > 0) {
+        PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_ACCUM);
+        hipLaunchKernelGGL((gauss_combine_kernel<T>), dim3((unsigned)tl.n_split), dim3(256), 0, ctx->stream, p);
+    }
+    PMF_HIP_CHECK(hipGetLastError());
+    return PMF_OK;
+}
+
+template <typename T, int KR>
+static void launch_solve_reg(pmf_ctx *ctx, const SolveParams<T> &sp) {
+    dim3 grid((unsigned)((sp.n + 3) / 4));
+    hipLaunchKernelGGL((gauss_solve_reg_kernel<T, KR>), grid, dim3(256),
+                       (size_t)4 * ctx->cov_stride * sizeof(T), ctx->stream, sp);
+}
+
+template <typename T>
+static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double sigma2, double eta2) {
+    const PmfSideIndex &ix = ctx->index[side];
+    PMF_REQUIRE(sigma2 > 0 && eta2 > 0, PMF_EINVAL, "pmf_gauss_factor_sweep: variances must be positive");
+    int rc;
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gauss_factor_finalize"))) return rc;
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_COV, "pmf_gauss_factor_finalize"))) return rc;
+    SolveParams<T> sp;
+    const int width = ctx->cov_stride + ctx->kpad;
+    if (stats) {
+        sp.rows = nullptr;
+        sp.n = ctx->rows[side];
+        sp.src_s = (const T *)stats;
+        sp.src_s_stride = width;
+        sp.src_w = (const T *)stats + ctx->cov_stride;
+        sp.src_w_stride = width;
+    } else {
+        sp.rows = ix.d_nonempty;
+        sp.n = ix.n_nonempty;
+        sp.src_s = (const T *)ctx->arr[side][PMF_ARR_COV];
+        sp.src_s_stride = ctx->cov_stride;
+        sp.src_w = (const T *)ctx->arr[side][PMF_ARR_FACTOR];
+        sp.src_w_stride = ctx->kpad;
+    }
+    sp.cov = (T *)ctx->arr[side][PMF_ARR_COV];
+    sp.factor = (T *)ctx->arr[side][PMF_ARR_FACTOR];
+    sp.inv_sigma2 = (T)(1.0 / sigma2);
+    sp.inv_eta2 = (T)(1.0 / eta2);
+    sp.K = ctx->K;
+    sp.kpad = ctx->kpad;
+    sp.cov_stride = ctx->cov_stride;
+    if (sp.n == 0) return PMF_OK;
+    PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_SOLVE);
+    if (ctx->K <= 8) launch_solve_reg<T, 8>(ctx, sp);
+    else if (ctx->K <= 16) launch_solve_reg<T, 16>(ctx, sp);
+    else if (ctx->K <= 32) launch_solve_reg<T, 32>(ctx, sp);
+    else if (ctx->K <= 64) launch_solve_reg<T, 64>(ctx, sp);
+    else {
+        const int K = ctx->K;
+        size_t smem = ((size_t)K * (K + 1) + 3 * K) * sizeof(T);
+        hipError_t e = hipFuncSetAttribute((const void *)gauss_solve_lds_kernel<T>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            pmf_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", smem, hipGetErrorString(e));
+            return PMF_EHIP;
+        }
+        hipLaunchKernelGGL((gauss_solve_lds_kernel<T>), dim3((unsigned)sp.n), dim3(256), smem, ctx->stream, sp);
+    }
+    PMF_HIP_CHECK(hipGetLastError());
+    return PMF_OK;
+}
+
+extern "C" int pmf_gauss_factor_sweep(pmf_ctx *ctx, int side, double sigma2, double eta2) {
+    GAUSS_PROLOGUE("pmf_gauss_factor_sweep");
+    int rc;
+    if (ctx->dtype == PMF_F64) {
+        if ((rc = run_factor_accumulate<double>(ctx, side, nullptr))) return rc;
+        return run_factor_solve<double>(ctx, side, nullptr, sigma2, eta2);
+    }
+    if ((rc = run_factor_accumulate<float>(ctx, side, nullptr))) return rc;
+    return run_factor_solve<float>(ctx, side, nullptr, sigma2, eta2);
+}
+
+extern "C" int pmf_gauss_factor_accumulate(pmf_ctx *ctx, int side, void *stats_dev) {
+    GAUSS_PROLOGUE("pmf_gauss_factor_accumulate");
+    PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gauss_factor_accumulate: null stats buffer");
+    if (ctx->dtype == PMF_F64) return run_factor_accumulate<double>(ctx, side, stats_dev);
+    return run_factor_accumulate<float>(ctx, side, stats_dev);
+}
+
+extern "C" int pmf_gauss_factor_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,
+                                         double eta2) {
+    GAUSS_PROLOGUE("pmf_gauss_factor_finalize");
+    PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gauss_factor_finalize: null stats buffer");
+    if (ctx->dtype == PMF_F64) return run_factor_solve<double>(ctx, side, stats_dev, sigma2, eta2);
+    return run_factor_solve<float>(ctx, side, stats_dev, sigma2, eta2);
+}
+
+// ---- bias ------------------------------------------------------------------
+template <typename T, int LPR>
+static void launch_bias(pmf_ctx *ctx, const BiasParams<T> &p, bool stats) {
+    constexpr int G = 256 / LPR;
+    dim3 grid((unsigned)((p.n_tasks + G - 1) / G));
+    if (stats) hipLaunchKernelGGL((gauss_bias_kernel<T, LPR, true>), grid, dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((gauss_bias_kernel<T, LPR, false>), grid, dim3(256), 0, ctx->stream, p);
+}
+
+// mode 0 fused, 1 accumulate to stats, 2 finalize from stats
+template <typename T>
+static int run_bias(pmf_ctx *ctx, int side, int mode, void *stats, double sigma2, double eta_bias2) {
+    const int other = 1 - side;
+    const PmfSideIndex &ix = ctx->index[side];
+    const PmfTaskList &tl = ix.bias_tasks;
+    int rc;
+    PMF_REQUIRE(ix.d_ptr, PMF_EINVAL, "pmf_gauss_bias_sweep: ratings have not been set");
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gauss_bias_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, other, PMF_ARR_FACTOR, "pmf_gauss_bias_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, side, PMF_ARR_BIAS, "pmf_gauss_bias_sweep"))) return rc;
+    if ((rc = pmf_require_array(ctx, other, PMF_ARR_BIAS, "pmf_gauss_bias_sweep"))) return rc;
+    if (mode != 1) PMF_REQUIRE(sigma2 > 0 && eta_bias2 > 0, PMF_EINVAL, "pmf_gauss_bias_sweep: variances must be positive");
+    if (mode != 2 && tl.n_slots > 0)
+        if ((rc = pmf_ensure_partial(ctx, (size_t)tl.n_slots * sizeof(T)))) return rc;
+    BiasParams<T> p;
+    p.tasks = tl.d_tasks;
+    p.n_tasks = tl.n_tasks;
+    p.split = tl.d_split;
+    p.other = ix.d_other;
+    p.val = (const T *)ix.d_val;
+    p.factor_self = (const T *)ctx->arr[side][PMF_ARR_FACTOR];
+    p.factor_other = (const T *)ctx->arr[other][PMF_ARR_FACTOR];
+    p.bias_self = (T *)ctx->arr[side][PMF_ARR_BIAS];
+    p.bias_other = (const T *)ctx->arr[other][PMF_ARR_BIAS];
+    p.partial = (T *)ctx->d_partial;
+    p.stats = (T *)stats;
+    p.inv_sigma2 = mode == 1 ? (T)1 : (T)(1.0 / sigma2);
+    p.inv_eta_bias2 = mode == 1 ? (T)1 : (T)(1.0 / eta_bias2);
+    p.kpad = ctx->kpad;
+    p.rows = ctx->rows[side];
+    PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_BIAS);
+    if (mode == 2) {
+        dim3 grid((unsigned)((p.rows + 255) / 256));
+        hipLaunchKernelGGL((gauss_bias_finalize_all_kernel<T>), grid, dim3(256), 0, ctx->stream, p);
+        PMF_HIP_CHECK(hipGetLastError());
+        return PMF_OK;
+    }
+    if (mode == 1)
+        PMF_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)p.rows * 2 * sizeof(T), ctx->stream));
+    if (tl.n_tasks > 0) {
+        switch (pmf_lanes_per_row(ctx->kpad)) {
+            case 1: launch_bias<T, 1>(ctx, p, mode == 1); break;
+            case 2: launch_bias<T, 2>(ctx, p, mode == 1); break;
+            case 4: launch_bias<T, 4>(ctx, p, mode == 1); break;
+            case 8: launch_bias<T, 8>(ctx, p, mode == 1); break;
+            case 16: launch_bias<T, 16>(ctx, p, mode == 1); break;
+            case 32: launch_bias<T, 32>(ctx, p, mode == 1); break;
+            default: launch_bias<T, 64>(ctx, p, mode == 1); break;
+        }
+    }
+    if (tl.n_split > 0) {
+        dim3 grid((unsigned)((tl.n_split + 255) / 256));
+        if (mode == 1)
+            hipLaunchKernelGGL((gauss_bias_split_kernel<T, true>), grid, dim3(256), 0, ctx->stream, p, tl.n_split, ix.d_ptr);
+        else
+            hipLaunchKernelGGL((gauss_bias_split_kernel<T, false>), grid, dim3(256), 0, ctx->stream, p, tl.n_split, ix.d_ptr);
+    }
+    PMF_HIP_CHECK(hipGetLastError());
+    return PMF_OK;
+}
+
+extern "C" int pmf_gauss_bias_sweep(pmf_ctx *ctx, int side, double sigma2, double eta_bias2) {
+    GAUSS_PROLOGUE("pmf_gauss_bias_sweep");
+    if (ctx->dtype == PMF_F64) return run_bias<double>(ctx, side, 0, nullptr, sigma2, eta_bias2);
+    return run_bias<float>(ctx, side, 0, nullptr, sigma2, eta_bias2);
+}
+
+extern "C" int pmf_gauss_bias_accumulate(pmf_ctx *ctx, int side, void *stats_dev) {
+    GAUSS_PROLOGUE("pmf_gauss_bias_accumulate");
+    PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gauss_bias_accumulate: null stats buffer");
+    if (ctx->dtype == PMF_F64) return run_bias<double>(ctx, side, 1, stats_dev, 1, 1);
+    return run_bias<float>(ctx, side, 1, stats_dev, 1, 1);
+}
+
+extern "C" int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,
+                                       double eta_bias2) {
+    GAUSS_PROLOGUE("pmf_gauss_bias_finalize");
+    PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gauss_bias_finalize: null stats buffer");
+    if (ctx->dtype == PMF_F64) return run_bias<double>(ctx, side, 2, (void *)stats_dev, sigma2, eta_bias2);
+    return run_bias<float>(ctx, side, 2, (void *)stats_dev, sigma2, eta_bias2);
+}
+
+// placeholder until the top-k kernel lands (pmf_topk.hip)
+extern "C" int pmf_topk_items(pmf_ctx *, int64_t, const int32_t *, int, int, int32_t *, double *) {
+    pmf_set_error("pmf_topk_items: not implemented yet");
+    return PMF_EINVAL;
+}

@@ -69,6 +69,8 @@ struct PmfSideIndex {
     int32_t *d_other = nullptr;  // [nnz] id on the opposite side
     void *d_val = nullptr;       // [nnz] rating, context dtype
     std::vector<int64_t> h_ptr;  // host copy of ptr (task building)
+    int32_t *d_nonempty = nullptr;  // rows with at least one rating (Gaussian solve list)
+    int64_t n_nonempty = 0;
     PmfTaskList gamma_tasks;     // chunk = PMF_GAMMA_CHUNK, empty rows included
     PmfTaskList gauss_tasks;     // chunk = PMF_GAUSS_CHUNK, empty rows excluded
     PmfTaskList bias_tasks;      // chunk = PMF_GAMMA_CHUNK, empty rows excluded
@@ -122,7 +124,7 @@ struct pmf_ctx {
 };
 
 #define PMF_GAMMA_CHUNK 256
-#define PMF_GAUSS_CHUNK 128
+#define PMF_GAUSS_CHUNK 512
 
 int pmf_dev_alloc(pmf_ctx *ctx, void **p, size_t bytes);
 void pmf_dev_free(pmf_ctx *ctx, void *p, size_t bytes);

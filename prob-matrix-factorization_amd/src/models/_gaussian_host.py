@@ -1,0 +1,133 @@
+"""Host logic shared by the two Gaussian CAVI classes (with / without biases).
+
+Iteration order, early-stop rule and verbose lines follow the reference
+(`gaussian_mf_cavi_bias.py:91-286`, bias-free twin `gaussian_mf_cavi.py:81-200`);
+each half-sweep is one C-ABI call (`pmf_gauss_factor_sweep`,
+`pmf_gauss_bias_sweep`)."""
+import numpy as np
+
+from src.evaluation.metrics import macro_mae, rmse
+from src.models._device_model import ITEM, USER, DeviceModel, frame_arrays
+from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR
+
+
+class GaussianHost(DeviceModel):
+    def __init__(self, config, dtype=None, device=None):
+        super().__init__(config, dtype, device)
+        self.m_theta = self.m_beta = None
+        self._V_theta = self._V_beta = None
+        self.global_mean = 0.0
+        if self._uses_bias:
+            self.m_user_bias = self.m_item_bias = None
+
+    # The covariance stacks are rows x K x K float64 on the host (32 GB at
+    # 1M x 64 x 64): they stay packed on the device and are materialised only
+    # when the attribute is read.
+    @property
+    def V_theta(self):
+        if self._V_theta is None and self._ctx is not None:
+            self._V_theta = self._ctx.get_array(USER, ARR_COV)
+        return self._V_theta
+
+    @V_theta.setter
+    def V_theta(self, value):
+        self._V_theta = value
+
+    @property
+    def V_beta(self):
+        if self._V_beta is None and self._ctx is not None:
+            self._V_beta = self._ctx.get_array(ITEM, ARR_COV)
+        return self._V_beta
+
+    @V_beta.setter
+    def V_beta(self, value):
+        self._V_beta = value
+
+    def _initialize_variational_params(self):
+        """Reference draw order (gaussian_mf_cavi_bias.py:52-67): user means, item means."""
+        K = self.config.n_factors
+        rng = np.random.default_rng(self.config.random_state)
+        self.m_theta = 0.1 * rng.standard_normal((self.n_users, K))
+        self.m_beta = 0.1 * rng.standard_normal((self.n_items, K))
+        if self._uses_bias:
+            self.m_user_bias = np.zeros(self.n_users)
+            self.m_item_bias = np.zeros(self.n_items)
+        self._V_theta = self._V_beta = None
+
+    def _pull_state(self):
+        ctx = self._ctx
+        self.m_theta, self.m_beta = ctx.get_array(USER, ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
+        if self._uses_bias:
+            self.m_user_bias, self.m_item_bias = ctx.get_array(USER, ARR_BIAS), ctx.get_array(ITEM, ARR_BIAS)
+        self._V_theta = self._V_beta = None
+
+    def fit(self, train_df, val_df=None, global_mean=0.0):
+        cfg = self.config
+        self.global_mean = global_mean
+        self._infer_dimensions(train_df)
+        self._initialize_variational_params()
+        u, i, x = frame_arrays(train_df)
+        ctx = self._open_context(u, i, x)
+        ctx.set_array(USER, ARR_FACTOR, self.m_theta)
+        ctx.set_array(ITEM, ARR_FACTOR, self.m_beta)
+        ctx.set_cov_identity(USER, 1.0)
+        ctx.set_cov_identity(ITEM, 1.0)
+        if self._uses_bias:
+            ctx.set_array(USER, ARR_BIAS, self.m_user_bias)
+            ctx.set_array(ITEM, ARR_BIAS, self.m_item_bias)
+        monitor = self._monitor_setup(val_df, offset=global_mean, drop_unseen=True)
+        previous = None
+        for it in range(1, cfg.max_iter + 1):
+            if cfg.verbose:
+                print(f"\nCAVI iteration {it}/{cfg.max_iter}")
+            ctx.gauss_factor_sweep(USER, cfg.sigma2, cfg.eta_theta2)
+            ctx.gauss_factor_sweep(ITEM, cfg.sigma2, cfg.eta_beta2)
+            if self._uses_bias:
+                ctx.gauss_bias_sweep(USER, cfg.sigma2, cfg.eta_bias2)
+                ctx.gauss_bias_sweep(ITEM, cfg.sigma2, cfg.eta_bias2)
+            self.history_["iterations"] = it
+            if monitor is None:
+                continue
+            val_rmse, val_macro_mae = monitor()
+            self._record(val_rmse, val_macro_mae)
+            if cfg.verbose:
+                if self._uses_bias:
+                    print(f"Validation RMSE: {val_rmse:.4f} | MacroMAE: {val_macro_mae:.4f}")
+                else:
+                    print(f"Validation RMSE: {val_rmse:.4f}")
+            if previous is not None:
+                improvement = previous - val_rmse
+                if cfg.verbose:
+                    print(f"Improvement: {improvement:.6f}")
+                if improvement >= 0 and improvement < cfg.tol:  # gaussian_mf_cavi_bias.py:279
+                    if cfg.verbose:
+                        print("Early stopping: small improvement on validation.")
+                    self.history_["stopped_early"] = True
+                    break
+            previous = val_rmse
+        if self.history_["iterations"] > 0:
+            self._pull_state()
+        return self
+
+    def predict(self, user_ids, item_ids, global_mean=0.0):
+        return self._need_ctx().predict(np.asarray(user_ids, dtype=int), np.asarray(item_ids, dtype=int),
+                                        use_bias=self._uses_bias, offset=global_mean)
+
+    def _seen(self, df):
+        keep = (df["u"] < self.n_users) & (df["i"] < self.n_items)
+        return df[keep]
+
+    def evaluate_rmse(self, df, global_mean):
+        df = self._seen(df)
+        if df.empty:
+            print("Warning: No valid (u,i) pairs.")
+            return np.nan
+        y_true = df["rating"].to_numpy(dtype=float) + global_mean
+        return rmse(y_true, self.predict(df["u"].to_numpy(), df["i"].to_numpy(), global_mean))
+
+    def evaluate_macro_mae(self, df, global_mean):
+        df = self._seen(df)
+        if df.empty:
+            return np.nan
+        y_true = df["rating"].to_numpy(dtype=float) + global_mean
+        return macro_mae(y_true, self.predict(df["u"].to_numpy(), df["i"].to_numpy(), global_mean))

@@ -25,6 +25,11 @@ def skewed_problem(seed, U, I, N, rating_kind="count"):
     rng = np.random.default_rng(seed)
     u = rng.permutation(U)[np.floor(U * rng.random(N) ** 2.0).astype(np.int64)]
     i = rng.permutation(I)[np.floor(I * rng.random(N) ** 3.0).astype(np.int64)]
+    # ids that never occur -> empty rows (the last id stays: it defines the dimension)
+    for dead in (1, U // 2, U - 2):
+        u[u == dead] = 0
+    for dead in (2, I // 3):
+        i[i == dead] = 0
     u[0], i[0] = U - 1, I - 1
     r = rng.choice(6, size=N, p=[0.032, 0.006, 0.012, 0.036, 0.142, 0.772]).astype(np.float64)
     if rating_kind == "count":

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ratings/s per CAVI epoch on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload gaussian_mf|hpf_cavi]
+
+A "step" is one full CAVI iteration (all half-sweeps of the model) over the
+synthetic rating matrix of SURVEY.md section 8(d).  The default workload is
+BASELINE.json configs[1]: Gaussian MF (mean-field CAVI with user/item biases,
+the reference's `gaussian_mf_cavi_bias.GaussianMFCAVI`), K = 64, 1M users x
+100k items, 50M ratings, on one GPU.  With N > 1 (launched by torch.distributed.run,
+one rank per GPU) every rank holds its own 1M-user / 50M-rating shard (weak
+scaling), the item block is replicated and the per-item sufficient statistics
+are all-reduced over RCCL once per item half-sweep.
+
+Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
+`roofline` (dominant kernel: algorithmic bytes / live hipEvent time vs the 8 TB/s
+HBM peak) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "prob-matrix-factorization_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (n_users, n_items, nnz) per GPU, K, hyper-parameters (best_hyperparams.txt:3,5)
+    "gaussian_mf": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
+                        hp=dict(sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0),
+                        label="gaussian_mf_cavi_bias K=64, 1Mx100k synthetic, 50M ratings per GPU"),
+    "hpf_cavi": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
+                     hp=dict(a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0),
+                     label="hpf_cavi K=64, 1Mx100k synthetic, 50M ratings per GPU"),
+}
+SMALL = dict(U=100_000, I=10_000, N=5_000_000)  # --small: quick functional run
+
+
+def algorithmic_bytes(workload, U, I, N, K, elem=4):
+    """bytes one epoch must move at minimum.
+    Returns (total per iteration, per dominant-kernel launch summed over the two
+    sides).  fp32 values, int32 indices."""
+    kp = K * (K + 1) // 2
+    if workload == "gaussian_mf":
+        per_rating_factor = elem * K + elem * kp + 12   # mean row + packed cov + idx + rating + bias
+        per_rating_bias = elem * K + 12
+        per_row = elem * kp + elem * K + 8
+        total = N * (2 * per_rating_factor + 2 * per_rating_bias) + (U + I) * per_row
+        dominant = 2 * N * per_rating_factor + (U + I) * (elem * kp + elem * K)  # two accumulate launches
+        return total, dominant
+    per_rating = elem * K + 8
+    total = N * 2 * per_rating + (U + I) * 4 * elem * K
+    return total, total
+
+
+def cpu_baseline(workload, K, hp):
+    """The CPU oracle's per-row loop (the reference's loop structure) on a
+    bounded sample of the same generator: ~10-30 s of single-thread CPU work."""
+    from oracle import cavi_oracle as orc
+    from pmf_hip.synth import synth_ratings
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    if workload == "gaussian_mf":
+        U, I, N = 4_000, 400, 200_000
+    else:
+        U, I, N = 100_000, 10_000, 5_000_000
+    u, i, r = synth_ratings(U, I, N, seed=7)
+    u, i = u.astype(np.int64), i.astype(np.int64)
+    U, I = orc.infer_dims(u, i)
+    idx = (orc.group_positions(u, U), orc.group_positions(i, I))
+
+    def run():
+        t0 = time.perf_counter()
+        if workload == "gaussian_mf":
+            st = orc.init_gaussian(U, I, K, 0, True)
+            orc.gaussian_iteration(st, idx, u, i, r - r.mean(), hp["sigma2"], hp["eta_theta2"],
+                                   hp["eta_beta2"], hp["eta_bias2"])
+        else:
+            st = orc.init_hpf(U, I, K, hp["a"], hp["a_prime"], hp["b_prime"], hp["c"], hp["c_prime"],
+                              hp["d_prime"], 0)
+            t0 = time.perf_counter()
+            orc.hpf_iteration(st, idx, u, i, r + 1.0, hp["a"], hp["b_prime"], hp["c"], hp["d_prime"])
+        return time.perf_counter() - t0
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            dt = run()
+    else:
+        dt = run()
+    return {"value": N / dt, "unit": "ratings/s", "cores": 1, "kind": "port",
+            "sample": f"1 iteration of the oracle's per-row NumPy loop, {U}x{I}, {N} ratings, K={K} "
+                      f"(same generator), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="gaussian_mf")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--small", action="store_true", help="1/10 size functional run (not a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER, dist as pdist
+    from pmf_hip.synth import BASE_SEED, synth_ratings
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.init_process_group(backend="nccl", device_id=device)
+        comm = pdist.Comm()
+
+    w = dict(WORKLOADS[args.workload])
+    if args.small:
+        w.update(SMALL)
+    U, I, N, K, hp = w["U"], w["I"], w["N"], w["K"], w["hp"]
+
+    # ---- data + state (untimed) ------------------------------------------
+    t0 = time.time()
+    u, i, r = synth_ratings(U, I, N, seed=BASE_SEED + rank)
+    t_gen = time.time() - t0
+    ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(42)
+    t0 = time.time()
+    if args.workload == "gaussian_mf":
+        gm = float(r.mean())
+        ctx.set_ratings(u, i, r - gm)  # centred as compare_models.py:54-65
+    else:
+        ctx.set_ratings(u, i, r + 1.0)  # +1 shift as compare_models.py:180-185
+    t_csr = time.time() - t0
+    del u, i, r
+    stats_item = stats_bias = None
+    if args.workload == "gaussian_mf":
+        # gaussian_mf_cavi_bias.py:52-67 initial state
+        ctx.set_array(USER, ARR_FACTOR, 0.1 * rng.standard_normal((U, K)))
+        ctx.set_array(ITEM, ARR_FACTOR, 0.1 * np.random.default_rng(43).standard_normal((I, K)))
+        ctx.set_cov_identity(USER, 1.0)
+        ctx.set_cov_identity(ITEM, 1.0)
+        ctx.set_array(USER, ARR_BIAS, np.zeros(U))
+        ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
+        if comm is not None:
+            stats_item, stats_bias = pdist.gauss_stats(ctx, device)
+
+        def step():
+            pdist.gaussian_iteration(ctx, comm, stats_item, stats_bias, hp["sigma2"], hp["eta_theta2"],
+                                     hp["eta_beta2"], hp["eta_bias2"])
+        dominant = "gauss_accum"
+    else:
+        # hpf_cavi.py:66-89 initial state
+        ctx.set_array(USER, ARR_FACTOR, (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K))))
+        r2 = np.random.default_rng(43)
+        ctx.set_array(ITEM, ARR_FACTOR, (hp["c"] + r2.gamma(1.0, 0.1, (I, K))) / (hp["d_prime"] + r2.gamma(1.0, 0.1, (I, K))))
+        ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, (hp["a_prime"] + K * hp["a"]) / hp["b_prime"]))
+        ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, (hp["c_prime"] + K * hp["c"]) / hp["d_prime"]))
+        if comm is not None:
+            stats_item = pdist.gamma_stats(ctx, device)
+        up = (hp["a"], 0.0, True, hp["a_prime"] + K * hp["a"], hp["b_prime"])
+        ip = (hp["c"], 0.0, True, hp["c_prime"] + K * hp["c"], hp["d_prime"])
+
+        def step():
+            pdist.gamma_iteration(ctx, comm, stats_item, up, ip)
+        dominant = "gamma_sweep"
+
+    def fence():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_get()
+    ctx.prof_enable(False)
+
+    if comm is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        import torch.distributed as tdist
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if comm is not None:
+            comm.barrier()
+            import torch.distributed as tdist
+            tdist.destroy_process_group()
+        return
+
+    elem = 4 if args.dtype == "f32" else 8
+    total_bytes, dom_bytes = algorithmic_bytes(args.workload, U, I, N, K, elem)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * N * args.steps / elapsed
+    dom_ms, dom_n = prof[dominant]
+    per_iter_launches = 2
+    achieved = (dom_bytes / per_iter_launches) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.workload}:{dominant}")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "ratings/sec (epoch) Gaussian-MF K=64" if args.workload == "gaussian_mf"
+                  else "ratings/sec (epoch) HPF-CAVI K=64",
+        "value": value, "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": w["label"] + (" [--small]" if args.small else ""), "n_users_per_gpu": U,
+                   "n_items": I, "ratings_per_gpu": N, "n_factors": K,
+                   "parallelism": f"user-range rating shards x{world}, item statistics all-reduce (RCCL)"
+                                  if world > 1 else "single GPU",
+                   "epoch_algorithmic_GB": total_bytes / 1e9,
+                   "epoch_fraction_of_hbm_roofline": (total_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS},
+        "roofline": {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n},
+        "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+        "setup_s": {"generate": t_gen, "csr_build_and_upload": t_csr},
+        "device_GB": ctx.device_bytes() / 1e9,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.workload, K, hp)
+    print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,7 +76,8 @@ extern "C" {
 #define PMF_KERNEL_EVAL 5          /* fused predict + error reduction */
 #define PMF_KERNEL_PREDICT 6
 #define PMF_KERNEL_TOPK 7
-#define PMF_KERNEL_COUNT 8
+#define PMF_KERNEL_GAUSS_COMBINE 8 /* split-row partial sums -> row sums */
+#define PMF_KERNEL_COUNT 9
 
 typedef struct pmf_ctx pmf_ctx;
 

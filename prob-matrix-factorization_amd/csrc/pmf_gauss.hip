@@ -616,7 +616,7 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats) {
                                (size_t)4 * ctx->kpad * sizeof(T), ctx->stream, p);
     }
     if (tl.n_split > 0) {
-        PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_ACCUM);
+        PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_COMBINE);
         hipLaunchKernelGGL((gauss_combine_kernel<T>), dim3((unsigned)tl.n_split), dim3(256), 0, ctx->stream, p);
     }
     PMF_HIP_CHECK(hipGetLastError());

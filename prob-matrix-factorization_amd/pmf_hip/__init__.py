@@ -18,7 +18,7 @@ F32, F64 = 0, 1
 USER, ITEM = 0, 1
 ARR_FACTOR, ARR_SHAPE, ARR_RATE, ARR_PRIOR_RATE, ARR_HYPER_RATE, ARR_COV, ARR_BIAS = range(7)
 KERNEL_NAMES = ("gamma_sweep", "gamma_final", "gauss_accum", "gauss_solve", "gauss_bias",
-                "eval", "predict", "topk")
+                "eval", "predict", "topk", "gauss_combine")
 MAX_LABELS = 32
 
 

@@ -1,0 +1,123 @@
+"""Multi-GPU orchestration of one CAVI iteration.
+
+Ratings are sharded by USER RANGE: rank g owns a contiguous block of users,
+all of their ratings and their theta-side state; the item-side state is
+replicated.  The user half-sweeps are purely local.  An item half-sweep is
+
+    local raw sums over this rank's ratings  ->  all-reduce (RCCL)  ->  finalise
+
+so every rank ends each iteration with identical item factors.  The exchanged
+quantity is the per-item sufficient statistic, not a gradient: [I x 2Kpad] for
+Poisson/HPF, [I x (Kp + Kpad)] (packed normal matrix + right-hand side) and
+[I x 2] (bias) for the Gaussian model.
+
+The functions here only sequence engine calls and collectives.  `engine` is any
+object with the `Context` half-sweep methods (pmf_hip.Context on a GPU; the CPU
+tests drive the same code with an oracle-backed stand-in over gloo), `comm` is
+a `Comm` (or None for a single process).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import ITEM, USER
+
+
+class Comm:
+    """torch.distributed wrapper: backend 'nccl' (= RCCL on ROCm) for device
+    tensors, 'gloo' for the CPU tests."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, tensor):
+        self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+
+def shard_bounds(user_ids, n_users, world):
+    """User-range boundaries [b_0 = 0, ..., b_world = n_users] balanced by the
+    number of ratings per shard, not by the number of users."""
+    counts = np.bincount(np.asarray(user_ids, dtype=np.int64), minlength=n_users)
+    cum = np.cumsum(counts)
+    total = int(cum[-1]) if len(cum) else 0
+    bounds = [0]
+    for g in range(1, world):
+        target = total * g / world
+        b = int(np.searchsorted(cum, target, side="left")) + 1
+        bounds.append(min(max(b, bounds[-1]), n_users))
+    bounds.append(n_users)
+    return np.asarray(bounds, dtype=np.int64)
+
+
+def take_shard(user_ids, item_ids, ratings, bounds, rank):
+    """This rank's ratings with user ids made local to its range (original
+    order kept, so per-row summation order is unchanged)."""
+    u = np.asarray(user_ids)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    sel = (u >= lo) & (u < hi)
+    return u[sel] - lo, np.asarray(item_ids)[sel], np.asarray(ratings)[sel]
+
+
+# ---- one iteration per model ------------------------------------------------
+def gamma_iteration(engine, comm, stats_item, user_prior, item_prior):
+    """Poisson MF / HPF.  `*_prior` = (shape_prior, rate_prior, hierarchical,
+    hyper_shape, hyper_rate_prior) as taken by `gamma_sweep`.
+    `stats_item` is the [I x 2 x Kpad] buffer object with `.ptr` and `.tensor`."""
+    engine.gamma_sweep(USER, *user_prior)
+    if comm is None or comm.world == 1:
+        engine.gamma_sweep(ITEM, *item_prior)
+        return
+    engine.gamma_accumulate(ITEM, stats_item.ptr)
+    comm.all_reduce(stats_item.tensor)
+    engine.gamma_finalize(ITEM, stats_item.ptr, *item_prior)
+
+
+def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2, eta_beta2,
+                       eta_bias2=None):
+    """Gaussian MF (+ biases when eta_bias2 is given), order as
+    gaussian_mf_cavi_bias.py:129-263."""
+    single = comm is None or comm.world == 1
+    engine.gauss_factor_sweep(USER, sigma2, eta_theta2)
+    if single:
+        engine.gauss_factor_sweep(ITEM, sigma2, eta_beta2)
+    else:
+        engine.gauss_factor_accumulate(ITEM, stats_item.ptr)
+        comm.all_reduce(stats_item.tensor)
+        engine.gauss_factor_finalize(ITEM, stats_item.ptr, sigma2, eta_beta2)
+    if eta_bias2 is None:
+        return
+    engine.gauss_bias_sweep(USER, sigma2, eta_bias2)
+    if single:
+        engine.gauss_bias_sweep(ITEM, sigma2, eta_bias2)
+    else:
+        engine.gauss_bias_accumulate(ITEM, stats_bias.ptr)
+        comm.all_reduce(stats_bias.tensor)
+        engine.gauss_bias_finalize(ITEM, stats_bias.ptr, sigma2, eta_bias2)
+
+
+class DeviceStats:
+    """A device buffer owned by torch (so RCCL can all-reduce it) whose raw
+    pointer is handed to the C-ABI accumulate / finalize calls."""
+
+    def __init__(self, n_elems, np_dtype, device):
+        import torch
+        tdt = torch.float64 if np_dtype == np.float64 else torch.float32
+        self.tensor = torch.zeros(int(n_elems), dtype=tdt, device=device)
+        self.ptr = self.tensor.data_ptr()
+
+
+def gamma_stats(ctx, device):
+    return DeviceStats(ctx.n_items * 2 * ctx.kpad, ctx.np_dtype, device)
+
+
+def gauss_stats(ctx, device):
+    return (DeviceStats(ctx.n_items * (ctx.cov_stride + ctx.kpad), ctx.np_dtype, device),
+            DeviceStats(ctx.n_items * 2, ctx.np_dtype, device))

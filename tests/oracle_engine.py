@@ -1,0 +1,133 @@
+"""A CPU stand-in for `pmf_hip.Context` built on the oracle -- TEST ONLY.
+
+It exposes the half-sweep methods `pmf_hip.dist` sequences (fused, accumulate,
+finalize) so the multi-process orchestration can be exercised over gloo on a
+machine without a GPU.  `stats` "pointers" are NumPy views of the torch CPU
+tensors that get all-reduced."""
+import numpy as np
+
+from oracle import cavi_oracle as orc
+
+USER, ITEM = 0, 1
+
+
+class CpuStats:
+    def __init__(self, n_elems):
+        import torch
+        self.tensor = torch.zeros(int(n_elems), dtype=torch.float64)
+        self.ptr = self.tensor.numpy()  # shares memory with the tensor
+
+
+class OracleEngine:
+    def __init__(self, n_users, n_items, K, u, i, x):
+        self.n_users, self.n_items, self.K = n_users, n_items, K
+        self.kpad, self.cov_stride = K, K * K  # stats carry full K x K matrices here
+        self.u, self.i, self.x = np.asarray(u, np.int64), np.asarray(i, np.int64), np.asarray(x, np.float64)
+        self.idx = (orc.group_positions(self.u, n_users), orc.group_positions(self.i, n_items))
+        self.st = {}
+
+    # --- helpers ---------------------------------------------------------
+    def _sides(self, side):
+        ptr, pos = self.idx[side]
+        other_ids = self.i if side == USER else self.u
+        return ptr, pos, other_ids
+
+    # --- Poisson / HPF ---------------------------------------------------
+    def _gamma_sums(self, side):
+        ptr, pos, oid = self._sides(side)
+        me, ot = ("E_theta", "E_beta") if side == USER else ("E_beta", "E_theta")
+        a, b = orc.gamma_half_sweep_segsum(self.st[me], self.st[ot], ptr, pos, oid, self.x, 0.0, 0.0)
+        return a, b
+
+    def _gamma_apply(self, side, a, b, shape_prior, rate_prior, hier, hyper_shape, hyper_rate_prior):
+        s = "theta" if side == USER else "beta"
+        pr = "E_xi" if side == USER else "E_eta"
+        hr = "gamma_b_xi" if side == USER else "gamma_b_eta"
+        rp = self.st[pr][:, None] if hier else rate_prior
+        self.st[f"a_{s}"] = shape_prior + a
+        self.st[f"b_{s}"] = rp + b
+        self.st[f"E_{s}"] = self.st[f"a_{s}"] / self.st[f"b_{s}"]
+        if hier:
+            self.st[hr] = hyper_rate_prior + self.st[f"E_{s}"].sum(axis=1)
+            self.st[pr] = hyper_shape / self.st[hr]
+
+    def gamma_sweep(self, side, *prior):
+        a, b = self._gamma_sums(side)
+        self._gamma_apply(side, a, b, *prior)
+
+    def gamma_accumulate(self, side, stats):
+        a, b = self._gamma_sums(side)
+        stats[:] = np.stack([a, b], axis=1).reshape(-1)
+
+    def gamma_finalize(self, side, stats, *prior):
+        rows = self.n_users if side == USER else self.n_items
+        s = np.asarray(stats).reshape(rows, 2, self.K)
+        self._gamma_apply(side, s[:, 0], s[:, 1], *prior)
+
+    # --- Gaussian ----------------------------------------------------------
+    def _gauss_sums(self, side):
+        ptr, pos, oid = self._sides(side)
+        me, ot = ("theta", "beta") if side == USER else ("beta", "theta")
+        bs, bo = ("m_user_bias", "m_item_bias") if side == USER else ("m_item_bias", "m_user_bias")
+        n_rows = ptr.size - 1
+        o = oid[pos]
+        row_of = np.repeat(np.arange(n_rows), np.diff(ptr))
+        mo = self.st[f"m_{ot}"][o]
+        S = orc._segment_sum((self.st[f"V_{ot}"][o] + np.einsum("nk,nl->nkl", mo, mo)).reshape(len(o), -1), ptr)
+        resid = self.x[pos] - self.st[bs][row_of] - self.st[bo][o]
+        w = orc._segment_sum(mo * resid[:, None], ptr)
+        return S, w
+
+    def _gauss_apply(self, side, S, w, sigma2, eta2):
+        me = "theta" if side == USER else "beta"
+        K = self.K
+        S = S.reshape(-1, K, K)
+        live = S[:, 0, 0] != 0
+        V = np.linalg.inv(S[live] / sigma2 + np.eye(K) / eta2)
+        self.st[f"V_{me}"] = self.st[f"V_{me}"].copy()
+        self.st[f"m_{me}"] = self.st[f"m_{me}"].copy()
+        self.st[f"V_{me}"][live] = V
+        self.st[f"m_{me}"][live] = np.einsum("nkl,nl->nk", V, w[live]) / sigma2
+
+    def gauss_factor_sweep(self, side, sigma2, eta2):
+        S, w = self._gauss_sums(side)
+        self._gauss_apply(side, S, w, sigma2, eta2)
+
+    def gauss_factor_accumulate(self, side, stats):
+        S, w = self._gauss_sums(side)
+        stats[:] = np.concatenate([S, w], axis=1).reshape(-1)
+
+    def gauss_factor_finalize(self, side, stats, sigma2, eta2):
+        rows = self.n_users if side == USER else self.n_items
+        s = np.asarray(stats).reshape(rows, self.K * self.K + self.K)
+        self._gauss_apply(side, s[:, :self.K * self.K], s[:, self.K * self.K:], sigma2, eta2)
+
+    def _bias_sums(self, side):
+        ptr, pos, oid = self._sides(side)
+        me, ot = ("theta", "beta") if side == USER else ("beta", "theta")
+        bo = "m_item_bias" if side == USER else "m_user_bias"
+        n_rows = ptr.size - 1
+        o = oid[pos]
+        row_of = np.repeat(np.arange(n_rows), np.diff(ptr))
+        resid = self.x[pos] - self.st[bo][o] - np.einsum("nk,nk->n", self.st[f"m_{ot}"][o], self.st[f"m_{me}"][row_of])
+        return orc._segment_sum(resid[:, None], ptr)[:, 0], np.diff(ptr).astype(np.float64)
+
+    def _bias_apply(self, side, tot, cnt, sigma2, eta_bias2):
+        key = "m_user_bias" if side == USER else "m_item_bias"
+        out = self.st[key].copy()
+        nz = cnt > 0
+        var = 1.0 / (1.0 / eta_bias2 + cnt[nz] / sigma2)
+        out[nz] = var / sigma2 * tot[nz]
+        self.st[key] = out
+
+    def gauss_bias_sweep(self, side, sigma2, eta_bias2):
+        self._bias_apply(side, *self._bias_sums(side), sigma2, eta_bias2)
+
+    def gauss_bias_accumulate(self, side, stats):
+        tot, cnt = self._bias_sums(side)
+        stats[:] = np.stack([tot, cnt], axis=1).reshape(-1)
+
+    def gauss_bias_finalize(self, side, stats, sigma2, eta_bias2):
+        rows = self.n_users if side == USER else self.n_items
+        s = np.asarray(stats).reshape(rows, 2)
+        self._bias_apply(side, s[:, 0], s[:, 1], sigma2, eta_bias2)

@@ -1,0 +1,111 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the user-sharded iteration
+orchestration in pmf_hip.dist: shard -> local half-sweeps -> all-reduce of the
+item statistics -> finalise, against the unsharded oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem():
+    from helpers import skewed_problem
+    return skewed_problem(11, 400, 60, 6000, rating_kind="count")
+
+
+def _worker(rank, world, port, kind, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as tdist
+    from oracle import cavi_oracle as orc
+    from oracle_engine import CpuStats, OracleEngine
+    from pmf_hip import dist as pdist
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = pdist.Comm()
+    u, i, x = _problem()
+    U, I, K = 400, 60, 6
+    bounds = pdist.shard_bounds(u, U, world)
+    lu, li, lx = pdist.take_shard(u, i, x, bounds, rank)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    eng = OracleEngine(hi - lo, I, K, lu, li, lx)
+    if kind == "hpf":
+        st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, seed=1)
+        eng.st = {"E_theta": st["E_theta"][lo:hi], "E_beta": st["E_beta"], "E_xi": st["E_xi"][lo:hi],
+                  "E_eta": st["E_eta"]}
+        stats = CpuStats(I * 2 * K)
+        up = (0.3, 0.0, True, st["gamma_a_xi"], 5.0)
+        ip = (0.3, 0.0, True, st["gamma_a_eta"], 5.0)
+        for _ in range(3):
+            pdist.gamma_iteration(eng, comm, stats, up, ip)
+        res = {"E_theta": eng.st["E_theta"], "E_beta": eng.st["E_beta"], "E_xi": eng.st["E_xi"],
+               "E_eta": eng.st["E_eta"]}
+    else:
+        xc = lx - 4.0
+        eng.x = xc
+        st = orc.init_gaussian(U, I, K, seed=1, bias=True)
+        eng.st = {"m_theta": st["m_theta"][lo:hi], "V_theta": st["V_theta"][lo:hi], "m_beta": st["m_beta"],
+                  "V_beta": st["V_beta"], "m_user_bias": st["m_user_bias"][lo:hi], "m_item_bias": st["m_item_bias"]}
+        s_item, s_bias = CpuStats(I * (K * K + K)), CpuStats(I * 2)
+        for _ in range(3):
+            pdist.gaussian_iteration(eng, comm, s_item, s_bias, 0.3, 0.5, 0.5, 1.0)
+        res = {k: eng.st[k] for k in ("m_theta", "m_beta", "V_beta", "m_user_bias", "m_item_bias")}
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, **res)
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["hpf", "gauss"])
+def test_two_rank_sharded_iteration_matches_unsharded_oracle(kind, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import cavi_oracle as orc
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    u, i, x = _problem()
+    U, I, K = 400, 60, 6
+    idx = (orc.group_positions(u, U), orc.group_positions(i, I))
+    if kind == "hpf":
+        st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, seed=1)
+        for _ in range(3):
+            orc.hpf_iteration(st, idx, u, i, x, 0.3, 5.0, 0.3, 5.0, orc.gamma_half_sweep_segsum)
+        user_keys, item_keys = ["E_theta", "E_xi"], ["E_beta", "E_eta"]
+    else:
+        st = orc.init_gaussian(U, I, K, seed=1, bias=True)
+        for _ in range(3):
+            orc.gaussian_iteration(st, idx, u, i, x - 4.0, 0.3, 0.5, 0.5, 1.0, vectorised=True)
+        user_keys, item_keys = ["m_theta", "m_user_bias"], ["m_beta", "V_beta", "m_item_bias"]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert parts[0]["lo"] == 0 and parts[0]["hi"] == parts[1]["lo"] and parts[1]["hi"] == U
+    for k in user_keys:
+        got = np.concatenate([p[k] for p in parts], axis=0)
+        np.testing.assert_allclose(got, st[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    for k in item_keys:
+        for p in parts:  # replicated item state is identical on every rank
+            np.testing.assert_allclose(p[k], st[k], rtol=1e-10, atol=1e-12, err_msg=k)
+        assert np.array_equal(parts[0][k], parts[1][k])
+
+
+def test_shard_bounds_balance_ratings_not_rows():
+    sys.path.insert(0, os.path.join(ROOT, "prob-matrix-factorization_amd"))
+    from pmf_hip import dist as pdist
+    u, i, x = _problem()
+    for world in (1, 2, 3, 8):
+        b = pdist.shard_bounds(u, 400, world)
+        assert b[0] == 0 and b[-1] == 400 and np.all(np.diff(b) >= 0)
+        per = [np.sum((u >= b[g]) & (u < b[g + 1])) for g in range(world)]
+        assert sum(per) == len(u)
+        assert max(per) - min(per) <= np.bincount(u).max() + 1
+        total = 0
+        for g in range(world):
+            lu, li, lx = pdist.take_shard(u, i, x, b, g)
+            assert lu.min(initial=0) >= 0 and lu.max(initial=0) < max(b[g + 1] - b[g], 1)
+            total += len(lu)
+        assert total == len(u)

@@ -1,0 +1,120 @@
+"""Single-GPU check of the multi-GPU kernels: W logical user-range shards on
+one device, item statistics summed the way the RCCL all-reduce would, must
+reproduce the unsharded (fused-kernel) result."""
+import numpy as np
+import pytest
+
+from helpers import max_abs, rel_err, skewed_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _shards(u, i, x, U, W):
+    from pmf_hip import dist as pdist
+    b = pdist.shard_bounds(u, U, W)
+    return b, [pdist.take_shard(u, i, x, b, g) for g in range(W)]
+
+
+def _allreduce(stats):
+    total = stats[0].tensor.clone()
+    for s in stats[1:]:
+        total += s.tensor
+    for s in stats:
+        s.tensor.copy_(total)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-11), ("f32", 3e-5)])
+@pytest.mark.parametrize("K", [16, 64])
+def test_hpf_logical_shards_equal_single_context(K, dtype, tol):
+    import torch
+    import pmf_hip
+    from oracle import cavi_oracle as orc
+    from pmf_hip import ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER, dist as pdist
+    U, I, N, W = 2000, 300, 50000, 3
+    u, i, x = skewed_problem(3, U, I, N)
+    st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, seed=3)
+    up = (0.3, 0.0, True, st["gamma_a_xi"], 5.0)
+    ip = (0.3, 0.0, True, st["gamma_a_eta"], 5.0)
+    dev = torch.device("cuda", 0)
+
+    def new_ctx(n_users, uu, ii, xx, lo, hi):
+        c = pmf_hip.Context(n_users, I, K, dtype=dtype)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.set_ratings(uu, ii, xx)
+        c.set_array(USER, ARR_FACTOR, st["E_theta"][lo:hi]); c.set_array(ITEM, ARR_FACTOR, st["E_beta"])
+        c.set_array(USER, ARR_PRIOR_RATE, st["E_xi"][lo:hi]); c.set_array(ITEM, ARR_PRIOR_RATE, st["E_eta"])
+        return c
+
+    ref = new_ctx(U, u, i, x, 0, U)
+    b, parts = _shards(u, i, x, U, W)
+    ctxs = [new_ctx(int(b[g + 1] - b[g]), *parts[g], int(b[g]), int(b[g + 1])) for g in range(W)]
+    stats = [pdist.gamma_stats(c, dev) for c in ctxs]
+    for _ in range(3):
+        pdist.gamma_iteration(ref, None, None, up, ip)
+        for c in ctxs:
+            c.gamma_sweep(USER, *up)
+        for c, s in zip(ctxs, stats):
+            c.gamma_accumulate(ITEM, s.ptr)
+        torch.cuda.synchronize()
+        _allreduce(stats)
+        for c, s in zip(ctxs, stats):
+            c.gamma_finalize(ITEM, s.ptr, *ip)
+    want_u, want_i = ref.get_array(USER, ARR_FACTOR), ref.get_array(ITEM, ARR_FACTOR)
+    got_u = np.concatenate([c.get_array(USER, ARR_FACTOR) for c in ctxs])
+    assert rel_err(got_u, want_u) <= tol
+    for c in ctxs:
+        assert rel_err(c.get_array(ITEM, ARR_FACTOR), want_i) <= tol
+        assert rel_err(c.get_array(ITEM, ARR_PRIOR_RATE), ref.get_array(ITEM, ARR_PRIOR_RATE)) <= tol
+    assert np.array_equal(ctxs[0].get_array(ITEM, ARR_FACTOR), ctxs[1].get_array(ITEM, ARR_FACTOR))
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 2e-4)])
+@pytest.mark.parametrize("K", [16, 64])
+def test_gaussian_logical_shards_equal_single_context(K, dtype, tol):
+    import torch
+    import pmf_hip
+    from oracle import cavi_oracle as orc
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER, dist as pdist
+    U, I, N, W = 1500, 200, 30000, 3
+    u, i, x = skewed_problem(4, U, I, N, rating_kind="centered")
+    st = orc.init_gaussian(U, I, K, seed=2, bias=True)
+    dev = torch.device("cuda", 0)
+
+    def new_ctx(n_users, uu, ii, xx, lo, hi):
+        c = pmf_hip.Context(n_users, I, K, dtype=dtype)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.set_ratings(uu, ii, xx)
+        c.set_array(USER, ARR_FACTOR, st["m_theta"][lo:hi]); c.set_array(ITEM, ARR_FACTOR, st["m_beta"])
+        c.set_cov_identity(USER); c.set_cov_identity(ITEM)
+        c.set_array(USER, ARR_BIAS, np.zeros(n_users)); c.set_array(ITEM, ARR_BIAS, np.zeros(I))
+        return c
+
+    ref = new_ctx(U, u, i, x, 0, U)
+    b, parts = _shards(u, i, x, U, W)
+    ctxs = [new_ctx(int(b[g + 1] - b[g]), *parts[g], int(b[g]), int(b[g + 1])) for g in range(W)]
+    stats = [pdist.gauss_stats(c, dev) for c in ctxs]
+    for _ in range(2):
+        pdist.gaussian_iteration(ref, None, None, None, 0.3, 0.5, 0.5, 1.0)
+        for c in ctxs:
+            c.gauss_factor_sweep(USER, 0.3, 0.5)
+        for c, (s, _) in zip(ctxs, stats):
+            c.gauss_factor_accumulate(ITEM, s.ptr)
+        torch.cuda.synchronize()
+        _allreduce([s for s, _ in stats])
+        for c, (s, _) in zip(ctxs, stats):
+            c.gauss_factor_finalize(ITEM, s.ptr, 0.3, 0.5)
+        for c in ctxs:
+            c.gauss_bias_sweep(USER, 0.3, 1.0)
+        for c, (_, sb) in zip(ctxs, stats):
+            c.gauss_bias_accumulate(ITEM, sb.ptr)
+        torch.cuda.synchronize()
+        _allreduce([sb for _, sb in stats])
+        for c, (_, sb) in zip(ctxs, stats):
+            c.gauss_bias_finalize(ITEM, sb.ptr, 0.3, 1.0)
+    got_u = np.concatenate([c.get_array(USER, ARR_FACTOR) for c in ctxs])
+    assert max_abs(got_u, ref.get_array(USER, ARR_FACTOR)) <= tol
+    assert max_abs(np.concatenate([c.get_array(USER, ARR_BIAS) for c in ctxs]), ref.get_array(USER, ARR_BIAS)) <= tol
+    for c in ctxs:
+        assert max_abs(c.get_array(ITEM, ARR_FACTOR), ref.get_array(ITEM, ARR_FACTOR)) <= tol
+        assert max_abs(c.get_array(ITEM, ARR_BIAS), ref.get_array(ITEM, ARR_BIAS)) <= tol
+        assert max_abs(c.get_array(ITEM, ARR_COV), ref.get_array(ITEM, ARR_COV)) <= tol

@@ -1,0 +1,97 @@
+"""BASELINE-size runs (1M users x 100k items, 50M ratings, K = 64) checked
+through size-independent properties and through the oracle on sampled rows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+U, I, N, K = 1_000_000, 100_000, 50_000_000, 64
+
+
+@pytest.fixture(scope="module")
+def ratings():
+    from pmf_hip.synth import synth_ratings
+    return synth_ratings(U, I, N, seed=99)
+
+
+def test_hpf_full_size_invariants_and_sampled_rows(ratings):
+    """(1) allocation conservation: sum_k (shape[r,k] - prior) = sum of row r's
+    ratings whenever no rate was clamped, so the grand total equals sum(x);
+    (2) rate sums: sum_r (rate[r,k] - prior_r) = sum_j FACTOR_other[o_j, k];
+    (3) sampled rows (incl. the heaviest, split over thousands of chunks)
+    against the oracle's per-row update."""
+    import pmf_hip
+    from oracle import cavi_oracle as orc
+    from pmf_hip import ARR_FACTOR, ARR_PRIOR_RATE, ARR_RATE, ARR_SHAPE, ITEM, USER
+    u, i, r = ratings
+    x = r + 1.0
+    rng = np.random.default_rng(0)
+    Et = (0.3 + rng.gamma(1.0, 0.1, (U, K))) / (5.0 + rng.gamma(1.0, 0.1, (U, K)))
+    Eb = (0.3 + rng.gamma(1.0, 0.1, (I, K))) / (5.0 + rng.gamma(1.0, 0.1, (I, K)))
+    xi = 1.0 + rng.random(I)
+    with pmf_hip.Context(U, I, K, dtype="f32") as ctx:
+        ctx.set_ratings(u, i, x)
+        ctx.set_array(USER, ARR_FACTOR, Et); ctx.set_array(ITEM, ARR_FACTOR, Eb)
+        ctx.set_array(ITEM, ARR_PRIOR_RATE, xi)
+        ctx.gamma_sweep(ITEM, 0.3, 0.0, True, 5.0 + K * 0.3, 5.0)
+        shape, rate = ctx.get_array(ITEM, ARR_SHAPE), ctx.get_array(ITEM, ARR_RATE)
+        factor = ctx.get_array(ITEM, ARR_FACTOR)
+    assert np.sum(shape - 0.3) == pytest.approx(np.sum(x), rel=2e-6)
+    row_tot = np.bincount(i, weights=x, minlength=I)
+    np.testing.assert_allclose((shape - 0.3).sum(axis=1), row_tot, rtol=5e-5, atol=1e-3)
+    deg_u = np.bincount(u, minlength=U).astype(np.float64)
+    np.testing.assert_allclose((rate - xi[:, None]).sum(axis=0), deg_u @ Et.astype(np.float32).astype(np.float64),
+                               rtol=2e-6)
+    np.testing.assert_allclose(factor, shape / rate, rtol=2e-6)
+    deg_i = np.bincount(i, minlength=I)
+    rows = np.concatenate([[int(np.argmax(deg_i))], rng.choice(I, 12, replace=False)])
+    order = np.argsort(i, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(deg_i)])
+    for rr in rows:
+        sel = order[ptr[rr]:ptr[rr + 1]]
+        a, b = orc.gamma_half_sweep_rows(Eb[rr:rr + 1], Et, np.array([0, len(sel)]), np.arange(len(sel)),
+                                         u[sel].astype(np.int64), x[sel], 0.3, xi[rr])
+        np.testing.assert_allclose(shape[rr], a[0], rtol=3e-4)
+        np.testing.assert_allclose(rate[rr], b[0], rtol=3e-4)
+
+
+def test_gaussian_full_size_sampled_rows(ratings):
+    """One user half-sweep at full size; sampled users (heaviest included)
+    against the oracle's normal equations built from the same item state."""
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER
+    u, i, r = ratings
+    x = r - r.mean()
+    rng = np.random.default_rng(1)
+    m_beta = 0.1 * rng.standard_normal((I, K))
+    b_item = 0.05 * rng.standard_normal(I)
+    b_user = 0.05 * rng.standard_normal(U)
+    v_scale = 0.5
+    with pmf_hip.Context(U, I, K, dtype="f32") as ctx:
+        ctx.set_ratings(u, i, x)
+        ctx.set_array(USER, ARR_FACTOR, np.zeros((U, K))); ctx.set_array(ITEM, ARR_FACTOR, m_beta)
+        ctx.set_cov_identity(USER, 1.0); ctx.set_cov_identity(ITEM, v_scale)
+        ctx.set_array(USER, ARR_BIAS, b_user); ctx.set_array(ITEM, ARR_BIAS, b_item)
+        ctx.gauss_factor_sweep(USER, 0.3, 0.5)
+        m_theta = ctx.get_array(USER, ARR_FACTOR)
+        ctx.gauss_bias_sweep(USER, 0.3, 1.0)
+        b_new = ctx.get_array(USER, ARR_BIAS)
+        deg_u = np.bincount(u, minlength=U)
+        rows = np.concatenate([[int(np.argmax(deg_u))], rng.choice(U, 10, replace=False)])
+    order = np.argsort(u, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(deg_u)])
+    mb32 = m_beta.astype(np.float32).astype(np.float64)
+    for rr in rows:
+        sel = order[ptr[rr]:ptr[rr + 1]]
+        if len(sel) == 0:
+            assert not m_theta[rr].any()
+            continue
+        mo = mb32[i[sel]]
+        S = len(sel) * v_scale * np.eye(K) + mo.T @ mo
+        V = np.linalg.inv(np.eye(K) / 0.5 + S / 0.3)
+        resid = x[sel] - b_user[rr] - b_item[i[sel]]
+        want = V @ (mo * resid[:, None]).sum(axis=0) / 0.3
+        np.testing.assert_allclose(m_theta[rr], want, rtol=2e-3, atol=2e-5)
+        res_b = x[sel] - b_item[i[sel]] - mo @ m_theta[rr]
+        var = 1.0 / (1.0 + len(sel) / 0.3)
+        assert b_new[rr] == pytest.approx(var / 0.3 * res_b.sum(), rel=2e-3, abs=2e-5)

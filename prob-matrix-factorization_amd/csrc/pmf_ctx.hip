@@ -175,6 +175,7 @@ extern "C" int pmf_ctx_create(int device, int64_t n_users, int64_t n_items, int 
 static void free_tasks(pmf_ctx *ctx, PmfTaskList &t) {
     pmf_dev_free(ctx, t.d_tasks, (size_t)t.n_tasks * sizeof(PmfTask));
     pmf_dev_free(ctx, t.d_split, (size_t)t.n_split * sizeof(PmfSplitRow));
+    pmf_dev_free(ctx, t.d_split_rows, (size_t)t.n_split * sizeof(int32_t));
     t = PmfTaskList();
 }
 
@@ -320,8 +321,14 @@ static int upload_tasks(pmf_ctx *ctx, const std::vector<int64_t> &ptr, int64_t r
     if (rc) return rc;
     if (!tasks.empty())
         PMF_HIP_CHECK(hipMemcpy(out.d_tasks, tasks.data(), tasks.size() * sizeof(PmfTask), hipMemcpyHostToDevice));
-    if (!split.empty())
+    rc = pmf_dev_alloc(ctx, (void **)&out.d_split_rows, split.size() * sizeof(int32_t));
+    if (rc) return rc;
+    if (!split.empty()) {
         PMF_HIP_CHECK(hipMemcpy(out.d_split, split.data(), split.size() * sizeof(PmfSplitRow), hipMemcpyHostToDevice));
+        std::vector<int32_t> ids(split.size());
+        for (size_t k = 0; k < split.size(); ++k) ids[k] = split[k].row;
+        PMF_HIP_CHECK(hipMemcpy(out.d_split_rows, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return PMF_OK;
 }
 

@@ -141,6 +141,113 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
     }
 }
 
+template <typename T>
+struct SolveParams {
+    const int32_t *rows;  // list of rows to solve, or null = every row (skip rows with S == 0)
+    int64_t n;
+    const T *src_s;
+    int64_t src_s_stride;
+    const T *src_w;
+    int64_t src_w_stride;
+    T *cov;
+    T *factor;
+    T inv_sigma2, inv_eta2;
+    int K, kpad, cov_stride;
+};
+
+__device__ __forceinline__ float readlane_dyn(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ double readlane_dyn(double x, int lane) {
+    long long q = __builtin_bit_cast(long long, x);
+    int lo = __builtin_amdgcn_readlane((int)(q & 0xFFFFFFFFll), lane);
+    int hi = __builtin_amdgcn_readlane((int)(q >> 32), lane);
+    q = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, q);
+}
+
+
+// One wavefront per row, lane j = column j, B[i] = row (i + step) mod KR.
+// Symmetric sweep on the Jacobi-scaled matrix (unit diagonal => pivots in
+// (0, 1], which keeps the column update fma(-s, 1 - 1/d, s) = s/d free of
+// cancellation).  The pivot row is always register 0 because every update
+// writes row i into register i-1; after KR steps the rows are back in place
+// and B = -inverse.  `img` is the packed lower triangle of S in LDS, `wj` lane
+// j's right-hand side; writes the packed inverse and the mean.
+template <typename T, int KR>
+__device__ __forceinline__ void solve_from_image(const T *img, T wj, int K, int kpad, T inv_sigma2, T inv_eta2,
+                                                 T *vout, T *mout, int lane) {
+    const int j = lane;
+    T B[KR];
+    const int jc = j < K ? j : 0;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const int ic = i < K ? i : 0;
+        const int lo = ic < jc ? ic : jc, hi = ic < jc ? jc : ic;
+        T s = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
+        if (!(i < K && j < K)) s = (T)0;
+        if (i == j) s += (i < K) ? inv_eta2 : (T)1;
+        B[i] = s;
+    }
+    // Jacobi scaling g_j = 1/sqrt(P_jj)
+    T diag = (T)1;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const T dii = readlane_dyn(B[i], i);
+        if (j == i) diag = dii;
+    }
+    const T g = (T)1 / sqrt(diag);
+#pragma unroll
+    for (int i = 0; i < KR; ++i) B[i] = B[i] * g * readlane_dyn(g, i);
+
+    for (int k = 0; k < KR; ++k) {
+        const T v = B[0];
+        const T pinv = (T)1 / readlane_dyn(v, k);
+        const T u = v * pinv;
+        const T uc = (j == k) ? ((T)1 - pinv) : u;
+        // column k as scalars first (one batch of v_readlane into SGPRs), then the
+        // rank-1 update: back-to-back readlane -> use pairs cost a wait state each
+        constexpr int SB = KR < 32 ? KR : 32;
+#pragma unroll
+        for (int i0 = 1; i0 < KR; i0 += SB) {
+            T sc[SB];
+#pragma unroll
+            for (int q = 0; q < SB; ++q)
+                if (i0 + q < KR) sc[q] = readlane_dyn(B[i0 + q], k);
+#pragma unroll
+            for (int q = 0; q < SB; ++q)
+                if (i0 + q < KR) B[i0 + q - 1] = fma(-sc[q], uc, B[i0 + q]);
+        }
+        B[KR - 1] = (j == k) ? -pinv : u;
+    }
+    // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
+    T mj = (T)0;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const T vij = -B[i] * g * readlane_dyn(g, i);
+        mj = fma(vij, readlane_dyn(wj, i), mj);
+        if (i < K && j <= i) vout[i * (i + 1) / 2 + j] = vij;
+    }
+    if (j < kpad) mout[j] = (j < K) ? mj * inv_sigma2 : (T)0;
+}
+
+template <typename T, int KR>
+__global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
+    if (idx >= p.n) return;
+    const int row = p.rows ? rfl(p.rows[idx]) : (int)idx;
+    const T *S = p.src_s + (int64_t)row * p.src_s_stride;
+    if (!p.rows && S[0] == (T)0) return;  // no rating anywhere for this row
+    T *img = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * p.cov_stride;
+    for (int q = lane * PMF_VEC; q < p.cov_stride; q += 64 * PMF_VEC) store4(img + q, load4(S + q));
+    wave_lds_fence();
+    const T wj = (lane < p.K) ? p.src_w[(int64_t)row * p.src_w_stride + lane] : (T)0;
+    solve_from_image<T, KR>(img, wj, p.K, p.kpad, p.inv_sigma2, p.inv_eta2,
+                            p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, lane);
+}
+
 // ---------------------------------------------------------------------------
 // accumulate, K = 64 fp32: covariance rows on the VALU, m m^T on the MFMA pipe
 // ---------------------------------------------------------------------------
@@ -154,7 +261,9 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
 #define G64_CHUNKS 520
 #define G64_T 9
 
-__global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<float> p) {
+template <bool FUSE>
+__global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<float> p, float inv_sigma2,
+                                                                float inv_eta2, float *cov_self, float *factor_self) {
     __shared__ __align__(16) float lds[4][G64_KP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
@@ -229,6 +338,28 @@ __global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<flo
         if (c <= row) img[R1 * (R1 + 1) / 2 + 32 + c] = d11[r];
     }
     wave_lds_fence();
+    wlo += __shfl_xor(wlo, 32, 64);
+    whi += __shfl_xor(whi, 32, 64);
+    if (FUSE && t.slot < 0) {
+        // the row is complete: finish it here (S = image + covariance sums stays in
+        // LDS) while the other wavefronts of the CU keep streaming
+#pragma unroll
+        for (int s = 0; s < G64_T; ++s) {
+            const int q = lane + 64 * s;
+            if (q < G64_CHUNKS) {
+                float4 m = reinterpret_cast<float4 *>(img)[q];
+                m.x += acc[s].x;
+                m.y += acc[s].y;
+                m.z += acc[s].z;
+                m.w += acc[s].w;
+                reinterpret_cast<float4 *>(img)[q] = m;
+            }
+        }
+        wave_lds_fence();
+        solve_from_image<float, 64>(img, h ? whi : wlo, 64, 64, inv_sigma2, inv_eta2,
+                                    cov_self + (int64_t)t.row * G64_KP, factor_self + (int64_t)t.row * 64, lane);
+        return;
+    }
     float *out_s, *out_w;
     if (t.slot >= 0) {
         out_s = p.partial + (int64_t)t.slot * (G64_KP + 64);
@@ -250,8 +381,6 @@ __global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<flo
             reinterpret_cast<float4 *>(out_s)[q] = o;
         }
     }
-    wlo += __shfl_xor(wlo, 32, 64);
-    whi += __shfl_xor(whi, 32, 64);
     if (h == 0) {
         out_w[c] = wlo;
         out_w[32 + c] = whi;
@@ -263,112 +392,37 @@ __global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<flo
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gauss_combine_kernel(GaussParams<T> p) {
+    constexpr int UN = 8;
     const PmfSplitRow sr = p.split[blockIdx.x];
-    const int width = p.cov_stride + p.kpad;
+    const int width = p.cov_stride + p.kpad;  // multiple of PMF_VEC
     T *out_s = p.dst_s + (int64_t)sr.row * p.dst_s_stride;
     T *out_w = p.dst_w + (int64_t)sr.row * p.dst_w_stride;
-    for (int e = threadIdx.x; e < width; e += 256) {
-        const T *src = p.partial + (int64_t)sr.first_slot * width + e;
-        T s = (T)0;
-        for (int k = 0; k < sr.n_slots; ++k) s += src[(int64_t)k * width];
-        if (e < p.cov_stride) out_s[e] = s;
-        else out_w[e - p.cov_stride] = s;
+    const T *base = p.partial + (int64_t)sr.first_slot * width;
+    for (int e = threadIdx.x * PMF_VEC; e < width; e += 256 * PMF_VEC) {
+        Vec4<T> acc = zero4<T>();
+        int k = 0;
+        for (; k + UN <= sr.n_slots; k += UN) {
+            Vec4<T> v[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) v[q] = load4(base + (int64_t)(k + q) * width + e);
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+#pragma unroll
+                for (int c = 0; c < PMF_VEC; ++c) acc.v[c] += v[q].v[c];
+        }
+        for (; k < sr.n_slots; ++k) {
+            Vec4<T> v = load4(base + (int64_t)k * width + e);
+#pragma unroll
+            for (int c = 0; c < PMF_VEC; ++c) acc.v[c] += v.v[c];
+        }
+        if (e < p.cov_stride) store4(out_s + e, acc);
+        else store4(out_w + (e - p.cov_stride), acc);
     }
 }
 
 // ---------------------------------------------------------------------------
 // solve: V = inv(I/eta2 + S/sigma2), m = V w / sigma2
 // ---------------------------------------------------------------------------
-template <typename T>
-struct SolveParams {
-    const int32_t *rows;  // list of rows to solve, or null = every row (skip rows with S == 0)
-    int64_t n;
-    const T *src_s;
-    int64_t src_s_stride;
-    const T *src_w;
-    int64_t src_w_stride;
-    T *cov;
-    T *factor;
-    T inv_sigma2, inv_eta2;
-    int K, kpad, cov_stride;
-};
-
-__device__ __forceinline__ float readlane_dyn(float x, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
-}
-__device__ __forceinline__ double readlane_dyn(double x, int lane) {
-    long long q = __builtin_bit_cast(long long, x);
-    int lo = __builtin_amdgcn_readlane((int)(q & 0xFFFFFFFFll), lane);
-    int hi = __builtin_amdgcn_readlane((int)(q >> 32), lane);
-    q = ((long long)hi << 32) | (unsigned int)lo;
-    return __builtin_bit_cast(double, q);
-}
-
-// One wavefront per row, lane j = column j, B[i] = row (i + step) mod KR.
-// Symmetric sweep on the Jacobi-scaled matrix (unit diagonal => pivots in
-// (0, 1], which keeps the column update fma(-s, 1 - 1/d, s) = s/d free of
-// cancellation).  The pivot row is always register 0 because every update
-// writes row i into register i-1; after KR steps the rows are back in place
-// and B = -inverse.
-template <typename T, int KR>
-__global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
-    if (idx >= p.n) return;
-    const int row = p.rows ? rfl(p.rows[idx]) : (int)idx;
-    const T *S = p.src_s + (int64_t)row * p.src_s_stride;
-    if (!p.rows && S[0] == (T)0) return;  // no rating anywhere for this row
-    T *img = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * p.cov_stride;
-    for (int q = lane * PMF_VEC; q < p.cov_stride; q += 64 * PMF_VEC) store4(img + q, load4(S + q));
-    wave_lds_fence();
-    const int K = p.K, j = lane;
-    T B[KR];
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        T s = (T)0;
-        if (i < K && j < K) {
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            s = img[hi * (hi + 1) / 2 + lo] * p.inv_sigma2;
-        }
-        if (i == j) s += (i < K) ? p.inv_eta2 : (T)1;
-        B[i] = s;
-    }
-    // Jacobi scaling g_j = 1/sqrt(P_jj)
-    T diag = (T)1;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const T dii = readlane_dyn(B[i], i);
-        if (j == i) diag = dii;
-    }
-    const T g = (T)1 / sqrt(diag);
-#pragma unroll
-    for (int i = 0; i < KR; ++i) B[i] = B[i] * g * readlane_dyn(g, i);
-
-    for (int k = 0; k < KR; ++k) {
-        const T v = B[0];
-        const T pinv = (T)1 / readlane_dyn(v, k);
-        const T u = v * pinv;
-        const T uc = (j == k) ? ((T)1 - pinv) : u;
-#pragma unroll
-        for (int i = 1; i < KR; ++i) {
-            const T s = readlane_dyn(B[i], k);
-            B[i - 1] = fma(-s, uc, B[i]);
-        }
-        B[KR - 1] = (j == k) ? -pinv : u;
-    }
-    // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
-    const T wj = (j < K) ? p.src_w[(int64_t)row * p.src_w_stride + j] : (T)0;
-    T mj = (T)0;
-    T *vout = p.cov + (int64_t)row * p.cov_stride;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const T vij = -B[i] * g * readlane_dyn(g, i);
-        mj = fma(vij, readlane_dyn(wj, i), mj);
-        if (i < K && j <= i) vout[i * (i + 1) / 2 + j] = vij;
-    }
-    if (j < p.kpad) p.factor[(int64_t)row * p.kpad + j] = (j < K) ? mj * p.inv_sigma2 : (T)0;
-}
 
 // Generic solve for 64 < K <= 128: one block per row, full matrix in LDS.
 template <typename T>
@@ -559,8 +613,11 @@ static bool use_bias(const pmf_ctx *ctx) {
 }
 
 // mode 0: fused (sums in place, then solve)   mode 1: accumulate into stats
+// *fused is set when the kernel also solved every single-task row (K = 64 fp32,
+// not in stats mode); the caller then only solves the split rows.
 template <typename T>
-static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats) {
+static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sigma2, double eta2, bool *fused) {
+    *fused = false;
     const int other = 1 - side;
     const PmfSideIndex &ix = ctx->index[side];
     const PmfTaskList &tl = ix.gauss_tasks;
@@ -608,7 +665,15 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats) {
         if constexpr (std::is_same<T, float>::value) {
             if (ctx->K == 64 && !getenv("PMF_GAUSS_GENERIC")) {
                 fast = true;
-                hipLaunchKernelGGL(gauss_accum_k64_kernel, grid, dim3(256), 0, ctx->stream, p);
+                if (!stats && !getenv("PMF_GAUSS_UNFUSED")) {
+                    *fused = true;
+                    hipLaunchKernelGGL(gauss_accum_k64_kernel<true>, grid, dim3(256), 0, ctx->stream, p,
+                                       (float)(1.0 / sigma2), (float)(1.0 / eta2),
+                                       (float *)ctx->arr[side][PMF_ARR_COV], (float *)ctx->arr[side][PMF_ARR_FACTOR]);
+                } else {
+                    hipLaunchKernelGGL(gauss_accum_k64_kernel<false>, grid, dim3(256), 0, ctx->stream, p, 0.f, 0.f,
+                                       (float *)nullptr, (float *)nullptr);
+                }
             }
         }
         if (!fast)
@@ -631,7 +696,8 @@ static void launch_solve_reg(pmf_ctx *ctx, const SolveParams<T> &sp) {
 }
 
 template <typename T>
-static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double sigma2, double eta2) {
+static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double sigma2, double eta2,
+                            bool split_rows_only = false) {
     const PmfSideIndex &ix = ctx->index[side];
     PMF_REQUIRE(sigma2 > 0 && eta2 > 0, PMF_EINVAL, "pmf_gauss_factor_sweep: variances must be positive");
     int rc;
@@ -647,8 +713,8 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
         sp.src_w = (const T *)stats + ctx->cov_stride;
         sp.src_w_stride = width;
     } else {
-        sp.rows = ix.d_nonempty;
-        sp.n = ix.n_nonempty;
+        sp.rows = split_rows_only ? ix.gauss_tasks.d_split_rows : ix.d_nonempty;
+        sp.n = split_rows_only ? ix.gauss_tasks.n_split : ix.n_nonempty;
         sp.src_s = (const T *)ctx->arr[side][PMF_ARR_COV];
         sp.src_s_stride = ctx->cov_stride;
         sp.src_w = (const T *)ctx->arr[side][PMF_ARR_FACTOR];
@@ -684,20 +750,23 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
 
 extern "C" int pmf_gauss_factor_sweep(pmf_ctx *ctx, int side, double sigma2, double eta2) {
     GAUSS_PROLOGUE("pmf_gauss_factor_sweep");
+    PMF_REQUIRE(sigma2 > 0 && eta2 > 0, PMF_EINVAL, "pmf_gauss_factor_sweep: variances must be positive");
     int rc;
+    bool fused = false;
     if (ctx->dtype == PMF_F64) {
-        if ((rc = run_factor_accumulate<double>(ctx, side, nullptr))) return rc;
-        return run_factor_solve<double>(ctx, side, nullptr, sigma2, eta2);
+        if ((rc = run_factor_accumulate<double>(ctx, side, nullptr, sigma2, eta2, &fused))) return rc;
+        return run_factor_solve<double>(ctx, side, nullptr, sigma2, eta2, fused);
     }
-    if ((rc = run_factor_accumulate<float>(ctx, side, nullptr))) return rc;
-    return run_factor_solve<float>(ctx, side, nullptr, sigma2, eta2);
+    if ((rc = run_factor_accumulate<float>(ctx, side, nullptr, sigma2, eta2, &fused))) return rc;
+    return run_factor_solve<float>(ctx, side, nullptr, sigma2, eta2, fused);
 }
 
 extern "C" int pmf_gauss_factor_accumulate(pmf_ctx *ctx, int side, void *stats_dev) {
     GAUSS_PROLOGUE("pmf_gauss_factor_accumulate");
     PMF_REQUIRE(stats_dev, PMF_EINVAL, "pmf_gauss_factor_accumulate: null stats buffer");
-    if (ctx->dtype == PMF_F64) return run_factor_accumulate<double>(ctx, side, stats_dev);
-    return run_factor_accumulate<float>(ctx, side, stats_dev);
+    bool fused = false;
+    if (ctx->dtype == PMF_F64) return run_factor_accumulate<double>(ctx, side, stats_dev, 1.0, 1.0, &fused);
+    return run_factor_accumulate<float>(ctx, side, stats_dev, 1.0, 1.0, &fused);
 }
 
 extern "C" int pmf_gauss_factor_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,

@@ -61,6 +61,7 @@ struct PmfTaskList {
     int32_t max_len = 0;
     PmfTask *d_tasks = nullptr;
     PmfSplitRow *d_split = nullptr;
+    int32_t *d_split_rows = nullptr;  // row id of every split row (solve list)
 };
 
 // Ratings ordered by one side (CSR when side = user, CSC when side = item).

@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--small", action="store_true", help="1/10 size functional run (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path on a single-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -125,12 +128,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     comm = None
     if world > 1:
         import torch.distributed as tdist
-        tdist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            tdist.init_process_group(backend="nccl", device_id=device)
+        else:
+            tdist.init_process_group(backend=args.backend)
         comm = pdist.Comm()
 
     w = dict(WORKLOADS[args.workload])
@@ -224,7 +232,7 @@ def main():
     achieved = (dom_bytes / per_iter_launches) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not args.small and args.dtype == "f32":
         try:
             traffic = json.load(open(tpath)).get(f"{args.workload}:{dominant}")
         except Exception:

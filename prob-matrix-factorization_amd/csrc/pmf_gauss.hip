@@ -868,9 +868,3 @@ extern "C" int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats
     if (ctx->dtype == PMF_F64) return run_bias<double>(ctx, side, 2, (void *)stats_dev, sigma2, eta_bias2);
     return run_bias<float>(ctx, side, 2, (void *)stats_dev, sigma2, eta_bias2);
 }
-
-// placeholder until the top-k kernel lands (pmf_topk.hip)
-extern "C" int pmf_topk_items(pmf_ctx *, int64_t, const int32_t *, int, int, int32_t *, double *) {
-    pmf_set_error("pmf_topk_items: not implemented yet");
-    return PMF_EINVAL;
-}

@@ -99,6 +99,12 @@ class DeviceModel:
         self.history_["val_rmse"].append(rmse_v)
         self.history_["val_macro_mae"].append(mae_v)
 
+    def top_k_items(self, user_ids, k=10):
+        """Extension (no reference counterpart): the k highest-scoring items per
+        user under `predict`'s score, ties to the lower item id.  Returns
+        (items [n, k] int32, scores [n, k] float64)."""
+        return self._need_ctx().topk_items(np.asarray(user_ids, dtype=int), int(k), use_bias=self._uses_bias)
+
     def close(self):
         """Release the device context (predict is unavailable afterwards)."""
         if self._ctx is not None:

@@ -16,7 +16,8 @@ for w, (cls, kname) in dominant.items():
         if not files:
             continue
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
+        newest = max(files, key=os.path.getmtime)
+        for r in csv.DictReader(open(newest)):
             if r["Counter_Name"] == c:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():

@@ -57,6 +57,8 @@ extern "C" {
  *   COV      V_theta / V_beta        (gaussian_mf_cavi_bias.py:34,36)        [rows x K x K] on the
  *            host side; packed lower-triangular K(K+1)/2 per row on the device
  *   BIAS     m_user_bias / m_item_bias (gaussian_mf_cavi_bias.py:39-40)      [rows]
+ *   SCALE / SCALE_SHAPE / SCALE_RATE   E_phi, a_phi, b_phi / E_psi, a_psi, b_psi of the extended
+ *            Poisson model (poisson_mf_extended_cavi.py:34-45)                [rows]
  */
 #define PMF_ARR_FACTOR 0
 #define PMF_ARR_SHAPE 1
@@ -65,7 +67,10 @@ extern "C" {
 #define PMF_ARR_HYPER_RATE 4
 #define PMF_ARR_COV 5
 #define PMF_ARR_BIAS 6
-#define PMF_ARR_COUNT 7
+#define PMF_ARR_SCALE 7
+#define PMF_ARR_SCALE_SHAPE 8
+#define PMF_ARR_SCALE_RATE 9
+#define PMF_ARR_COUNT 10
 
 /* kernel classes for pmf_prof_get (live hipEvent timing on the context's stream) */
 #define PMF_KERNEL_GAMMA_SWEEP 0   /* Poisson/HPF half-sweep accumulate(+finalise) */
@@ -138,6 +143,19 @@ int pmf_set_cov_identity(pmf_ctx *ctx, int side, double scale);
 int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior,
                     int hierarchical, double hyper_shape, double hyper_rate_prior);
 
+/* Extended Poisson MF half-sweep, x ~ Poisson(phi_u psi_i theta_u.beta_i)
+ * (poisson_mf_extended_cavi.py:108-160 users, :163-215 items).  With s = SCALE of
+ * the other side:
+ *     SHAPE[r]  = a0 + sum_j x_j FACTOR_other[o_j] FACTOR_side[r] / (FACTOR_other[o_j].FACTOR_side[r])
+ *     RATE[r]   = b0 + sum_j s[o_j] FACTOR_other[o_j];        FACTOR[r] = SHAPE[r] / RATE[r]
+ *     SCALE_SHAPE[r] = a0 + sum_j x_j;
+ *     SCALE_RATE[r]  = b0 + sum_j s[o_j] (FACTOR_other[o_j] . FACTOR[r])   -- with the NEW FACTOR[r]
+ *     SCALE[r]       = SCALE_SHAPE[r] / SCALE_RATE[r]
+ * The rate is not clamped (the reference divides by the raw dot product).  Rows
+ * without ratings get the priors in SHAPE / RATE / SCALE_SHAPE / SCALE_RATE and keep
+ * FACTOR and SCALE (the reference `continue`s before recomputing them). */
+int pmf_gamma_ext_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior);
+
 /* Multi-GPU form of the same half-sweep (ratings sharded by user range,
  * SURVEY.md section 8e).  `accumulate` writes this rank's raw sums
  * [rows x 2 x Kpad] (shape sums, then rate sums; Kpad from pmf_ctx_kpad) into
@@ -178,8 +196,12 @@ int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, doubl
 /* ---- predict / evaluate -------------------------------------------------
  * `predict` (hpf_cavi.py:215-231, poisson_mf_cavi.py:221-241,
  * gaussian_mf_cavi_bias.py:291-316): out[n] = FACTOR_user[u].FACTOR_item[i]
- * (+ BIAS_user[u] + BIAS_item[i] when use_bias) for ids inside the trained
+ * (+ BIAS_user[u] + BIAS_item[i] when bit 0 of `use_bias` is set; multiplied by
+ * SCALE_user[u] SCALE_item[i] when bit 1 is set -- the extended Poisson model's
+ * predict, poisson_mf_extended_cavi.py:239-259) for ids inside the trained
  * dimensions, 0 otherwise; `offset` (global_mean) is added to every row. */
+#define PMF_PREDICT_BIAS 1
+#define PMF_PREDICT_SCALE 2
 int pmf_predict(pmf_ctx *ctx, int64_t n, const int32_t *user_ids, const int32_t *item_ids,
                 int use_bias, double offset, double *out);
 

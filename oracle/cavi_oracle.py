@@ -69,6 +69,24 @@ def init_poisson(n_users, n_items, K, a0, b0, seed):
     return st
 
 
+def init_poisson_ext(n_users, n_items, K, a0, b0, seed):
+    """poisson_mf_extended_cavi.py:57-75 -- four gamma draws: a_theta, a_beta,
+    a_phi, a_psi; all rates start at b0."""
+    rng = np.random.default_rng(seed)
+    st = {}
+    st["a_theta"] = a0 + rng.gamma(1.0, 0.1, size=(n_users, K))
+    st["a_beta"] = a0 + rng.gamma(1.0, 0.1, size=(n_items, K))
+    st["a_phi"] = a0 + rng.gamma(1.0, 0.1, size=n_users)
+    st["a_psi"] = a0 + rng.gamma(1.0, 0.1, size=n_items)
+    st["b_theta"] = b0 * np.ones((n_users, K))
+    st["b_beta"] = b0 * np.ones((n_items, K))
+    st["b_phi"] = b0 * np.ones(n_users)
+    st["b_psi"] = b0 * np.ones(n_items)
+    for name in ("theta", "beta", "phi", "psi"):
+        st[f"E_{name}"] = st[f"a_{name}"] / st[f"b_{name}"]
+    return st
+
+
 def init_hpf(n_users, n_items, K, a, a_prime, b_prime, c, c_prime, d_prime, seed):
     """hpf_cavi.py:66-89 -- four gamma draws in the order a_theta, b_theta,
     a_beta, b_beta; xi/eta shapes are scalars (Appendix A.3 of SURVEY.md)."""
@@ -162,6 +180,47 @@ def gamma_half_sweep_segsum(E_self, E_other, ptr, pos, other_ids, x, shape_prior
     shape = shape_prior + _segment_sum(share, ptr)
     rate = rate_prior[:, None] + _segment_sum(other, ptr)
     return shape, rate
+
+
+def gamma_ext_half_sweep_rows(E_self, S_self, E_other, S_other, ptr, pos, other_ids, x, a0, b0):
+    """One half-sweep of the extended Poisson model x ~ Poisson(phi psi theta.beta)
+    (poisson_mf_extended_cavi.py:108-160 users, :163-215 items).  Per non-empty row:
+        a[r]   = a0 + sum_j x_j * E_other[o_j] * E_self[r] / (E_other[o_j].E_self[r])   (no clamp)
+        b[r]   = b0 + sum_j S_other[o_j] * E_other[o_j]
+        E[r]   = a[r] / b[r]                      (row-local Gauss-Seidel: used right below)
+        sa[r]  = a0 + sum_j x_j ;  sb[r] = b0 + sum_j S_other[o_j] * (E_other[o_j].E[r]) ;  S[r] = sa/sb
+    Empty rows: a, b, sa, sb fall back to the priors but E[r] and S[r] KEEP their
+    values (the reference `continue`s before touching them).
+    Returns (a, b, E, sa, sb, S)."""
+    n_rows, K = E_self.shape
+    a, b, E = np.empty((n_rows, K)), np.empty((n_rows, K)), E_self.copy()
+    sa, sb, S = np.empty(n_rows), np.empty(n_rows), S_self.copy()
+    for r in range(n_rows):
+        sel = pos[ptr[r]:ptr[r + 1]]
+        if sel.size == 0:
+            a[r], b[r], sa[r], sb[r] = a0, b0, a0, b0
+            continue
+        other = E_other[other_ids[sel]]
+        scale = S_other[other_ids[sel]]
+        mine = E_self[r]
+        dots = other @ mine
+        a[r] = a0 + np.sum((x[sel][:, None] / dots[:, None]) * other * mine[None, :], axis=0)
+        b[r] = b0 + np.sum(other * scale[:, None], axis=0)
+        E[r] = a[r] / b[r]
+        sa[r] = a0 + np.sum(x[sel])
+        sb[r] = b0 + np.sum(scale * (other @ E[r]))
+        S[r] = sa[r] / sb[r]
+    return a, b, E, sa, sb, S
+
+
+def poisson_ext_iteration(st, idx, u, i, x, a0, b0):
+    """poisson_mf_extended_cavi.py:105-215: users (theta, phi) then items (beta, psi)."""
+    (uptr, upos), (iptr, ipos) = idx
+    (st["a_theta"], st["b_theta"], st["E_theta"], st["a_phi"], st["b_phi"], st["E_phi"]) = gamma_ext_half_sweep_rows(
+        st["E_theta"], st["E_phi"], st["E_beta"], st["E_psi"], uptr, upos, i, x, a0, b0)
+    (st["a_beta"], st["b_beta"], st["E_beta"], st["a_psi"], st["b_psi"], st["E_psi"]) = gamma_ext_half_sweep_rows(
+        st["E_beta"], st["E_psi"], st["E_theta"], st["E_phi"], iptr, ipos, u, x, a0, b0)
+    return st
 
 
 def poisson_iteration(st, idx, u, i, x, a0, b0, sweep=gamma_half_sweep_rows):
@@ -350,6 +409,17 @@ def gaussian_eval(st, val_u, val_i, val_x, global_mean, bias=True):
     return rmse(y, p), macro_mae(y, p)
 
 
+def ext_predict(st, user_ids, item_ids):
+    """poisson_mf_extended_cavi.py:239-259: phi_u psi_i theta_u.beta_i, 0 for unseen ids."""
+    user_ids = np.asarray(user_ids, dtype=np.int64)
+    item_ids = np.asarray(item_ids, dtype=np.int64)
+    out = np.zeros(len(user_ids))
+    ok = (user_ids < st["E_theta"].shape[0]) & (item_ids < st["E_beta"].shape[0])
+    uu, ii = user_ids[ok], item_ids[ok]
+    out[ok] = st["E_phi"][uu] * st["E_psi"][ii] * np.sum(st["E_theta"][uu] * st["E_beta"][ii], axis=1)
+    return out
+
+
 def gamma_eval(st, val_u, val_i, val_x):
     """hpf_cavi.py:233-241 / poisson_mf_cavi.py:243-251: no filtering -- rows
     with unseen ids count with a prediction of 0."""
@@ -372,7 +442,7 @@ def _stop_gauss(improvement, tol):
 
 def fit(kind, u, i, x, cfg, val=None, global_mean=0.0, vectorised=False):
     """Run `cfg['max_iter']` iterations of model `kind` ('poisson' | 'hpf' |
-    'gauss_bias' | 'gauss'); returns (state, history).  `val` = (u, i, rating)."""
+    'gauss_bias' | 'gauss' | 'poisson_ext'); returns (state, history).  `val` = (u, i, rating)."""
     u = np.asarray(u, dtype=np.int64)
     i = np.asarray(i, dtype=np.int64)
     x = np.asarray(x, dtype=np.float64)
@@ -385,6 +455,8 @@ def fit(kind, u, i, x, cfg, val=None, global_mean=0.0, vectorised=False):
     elif kind == "hpf":
         st = init_hpf(U, I, K, cfg["a"], cfg["a_prime"], cfg["b_prime"], cfg["c"],
                       cfg["c_prime"], cfg["d_prime"], seed)
+    elif kind == "poisson_ext":
+        st = init_poisson_ext(U, I, K, cfg["a0"], cfg["b0"], seed)
     else:
         st = init_gaussian(U, I, K, seed, bias=(kind == "gauss_bias"))
     hist = {"val_rmse": [], "val_macro_mae": [], "stopped_early": False, "iterations": 0}
@@ -394,6 +466,8 @@ def fit(kind, u, i, x, cfg, val=None, global_mean=0.0, vectorised=False):
             poisson_iteration(st, idx, u, i, x, cfg["a0"], cfg["b0"], gsweep)
         elif kind == "hpf":
             hpf_iteration(st, idx, u, i, x, cfg["a"], cfg["b_prime"], cfg["c"], cfg["d_prime"], gsweep)
+        elif kind == "poisson_ext":
+            poisson_ext_iteration(st, idx, u, i, x, cfg["a0"], cfg["b0"])
         else:
             gaussian_iteration(st, idx, u, i, x, cfg["sigma2"], cfg["eta_theta2"], cfg["eta_beta2"],
                                cfg.get("eta_bias2") if kind == "gauss_bias" else None, vectorised)
@@ -402,7 +476,10 @@ def fit(kind, u, i, x, cfg, val=None, global_mean=0.0, vectorised=False):
             continue
         vu, vi, vx = (np.asarray(val[0], dtype=np.int64), np.asarray(val[1], dtype=np.int64),
                       np.asarray(val[2], dtype=np.float64))
-        if kind in ("poisson", "hpf"):
+        if kind == "poisson_ext":
+            r, mm = rmse(vx, ext_predict(st, vu, vi)), float("nan")
+            stop = _stop_gamma
+        elif kind in ("poisson", "hpf"):
             r, mm = gamma_eval(st, vu, vi, vx)
             stop = _stop_gamma
         else:

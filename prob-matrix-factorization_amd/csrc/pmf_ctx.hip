@@ -105,7 +105,8 @@ size_t pmf_array_elems(const pmf_ctx *ctx, int side, int array) {
 }
 
 static const char *array_name(int array) {
-    static const char *n[] = {"FACTOR", "SHAPE", "RATE", "PRIOR_RATE", "HYPER_RATE", "COV", "BIAS"};
+    static const char *n[] = {"FACTOR", "SHAPE", "RATE", "PRIOR_RATE", "HYPER_RATE", "COV", "BIAS",
+                              "SCALE", "SCALE_SHAPE", "SCALE_RATE"};
     return (array >= 0 && array < PMF_ARR_COUNT) ? n[array] : "?";
 }
 

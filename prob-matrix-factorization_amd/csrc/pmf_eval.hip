@@ -14,6 +14,8 @@ struct PredictParams {
     const T *fi;
     const T *bu;  // null when biases are not used
     const T *bi;
+    const T *su;  // null unless the scalar factors of the extended Poisson model apply
+    const T *si;
     int64_t n_users, n_items;
     int kpad;
     double offset;
@@ -36,6 +38,7 @@ __device__ __forceinline__ double predict_pair(const PredictParams<T> &p, int64_
         d = fma(a.v[3], b.v[3], d);
     }
     d = group_sum<LPR>(d);
+    if (valid && p.su) d = p.su[u] * p.si[i] * d;
     if (valid && p.bu) d = p.bu[u] + p.bi[i] + d;
     return (valid ? (double)d : 0.0) + p.offset;
 }
@@ -116,10 +119,18 @@ static int fill_params(pmf_ctx *ctx, int use_bias, double offset, PredictParams<
     int rc;
     if ((rc = pmf_require_array(ctx, PMF_SIDE_USER, PMF_ARR_FACTOR, fn))) return rc;
     if ((rc = pmf_require_array(ctx, PMF_SIDE_ITEM, PMF_ARR_FACTOR, fn))) return rc;
+    const bool scale = (use_bias & PMF_PREDICT_SCALE) != 0;
+    use_bias &= PMF_PREDICT_BIAS;
     if (use_bias) {
         if ((rc = pmf_require_array(ctx, PMF_SIDE_USER, PMF_ARR_BIAS, fn))) return rc;
         if ((rc = pmf_require_array(ctx, PMF_SIDE_ITEM, PMF_ARR_BIAS, fn))) return rc;
     }
+    if (scale) {
+        if ((rc = pmf_require_array(ctx, PMF_SIDE_USER, PMF_ARR_SCALE, fn))) return rc;
+        if ((rc = pmf_require_array(ctx, PMF_SIDE_ITEM, PMF_ARR_SCALE, fn))) return rc;
+    }
+    p.su = scale ? (const T *)ctx->arr[PMF_SIDE_USER][PMF_ARR_SCALE] : nullptr;
+    p.si = scale ? (const T *)ctx->arr[PMF_SIDE_ITEM][PMF_ARR_SCALE] : nullptr;
     p.fu = (const T *)ctx->arr[PMF_SIDE_USER][PMF_ARR_FACTOR];
     p.fi = (const T *)ctx->arr[PMF_SIDE_ITEM][PMF_ARR_FACTOR];
     p.bu = use_bias ? (const T *)ctx->arr[PMF_SIDE_USER][PMF_ARR_BIAS] : nullptr;

@@ -25,7 +25,13 @@ struct GammaParams {
     T *rate;
     T *prior_rate_vec;  // E_xi / E_eta (HPF) or null
     T *hyper_rate;      // gamma_b_xi / gamma_b_eta (HPF) or null
-    T *partial;         // [n_slots][2][kpad]
+    // extended model (EXT): per-row scalar factors phi / psi
+    const T *scale_other;
+    T *scale_self;
+    T *scale_shape;
+    T *scale_rate;
+    int pw;             // partial slot width: 2*kpad (+ PMF_VEC carrying sum x when EXT)
+    T *partial;         // [n_slots][pw]
     T *stats;           // [rows][2][kpad], STATS mode only
     T shape_prior, rate_prior, hyper_shape, hyper_rate_prior;
     int hierarchical;
@@ -35,9 +41,9 @@ struct GammaParams {
 
 // shape = prior + sum, rate = prior_rate + sum, E = shape / rate, plus the
 // xi / eta update (hpf_cavi.py:155-159) when hierarchical.
-template <typename T, int LPR>
+template <typename T, int LPR, bool EXT>
 __device__ __forceinline__ void gamma_finalize_row(const GammaParams<T> &p, int row, int c, bool active,
-                                                   const Vec4<T> &sum_a, const Vec4<T> &sum_b) {
+                                                   const Vec4<T> &sum_a, const Vec4<T> &sum_b, T xsum, bool empty) {
     const int koff = c * PMF_VEC;
     const T rp = p.hierarchical ? p.prior_rate_vec[row] : p.rate_prior;
     Vec4<T> sh, rt, ex;
@@ -51,15 +57,25 @@ __device__ __forceinline__ void gamma_finalize_row(const GammaParams<T> &p, int 
         sh.v[e] = ok ? s : (T)0;
         rt.v[e] = ok ? r : (T)0;
         ex.v[e] = ok ? x : (T)0;
-        esum += ex.v[e];
+        esum += EXT ? ex.v[e] * sum_b.v[e] : ex.v[e];
     }
     if (active) {
         const int64_t at = (int64_t)row * p.kpad + koff;
         store4(p.shape + at, sh);
         store4(p.rate + at, rt);
-        store4(p.factor_self + at, ex);
+        if (!(EXT && empty)) store4(p.factor_self + at, ex);
     }
-    if (p.hierarchical) {
+    if (EXT) {
+        // phi / psi: shape a0 + sum x, rate b0 + sum_j s_j (other_j . FACTOR_new[row]) = b0 + FACTOR_new . sum_b
+        esum = group_sum<LPR>(esum);
+        if (c == 0) {
+            const T ss = p.shape_prior + xsum;
+            const T sr = p.rate_prior + (empty ? (T)0 : esum);
+            p.scale_shape[row] = ss;
+            p.scale_rate[row] = sr;
+            if (!empty) p.scale_self[row] = ss / sr;
+        }
+    } else if (p.hierarchical) {
         esum = group_sum<LPR>(esum);
         if (c == 0) {
             T hr = p.hyper_rate_prior + esum;
@@ -69,7 +85,7 @@ __device__ __forceinline__ void gamma_finalize_row(const GammaParams<T> &p, int 
     }
 }
 
-template <typename T, int LPR, bool STATS>
+template <typename T, int LPR, bool STATS, bool EXT>
 __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
     constexpr int G = 256 / LPR;
     constexpr int UN = LPR < 4 ? LPR : 4;
@@ -83,6 +99,7 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
 
     Vec4<T> self = active ? load4(p.factor_self + (int64_t)t.row * kpad + koff) : zero4<T>();
     Vec4<T> acc_a = zero4<T>(), acc_b = zero4<T>();
+    T xsum = (T)0;
     const int32_t *col = p.other + t.start;
     const T *val = p.val + t.start;
 
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
         }
         for (int tt = 0; tt < n; tt += UN) {
             int o[UN];
-            T xv[UN];
+            T xv[UN], sv[UN];
             Vec4<T> b[UN];
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
@@ -104,8 +121,10 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
                 xv[q] = __shfl(my_x, tt + q, LPR);
             }
 #pragma unroll
-            for (int q = 0; q < UN; ++q)
+            for (int q = 0; q < UN; ++q) {
                 b[q] = active ? load4(p.factor_other + (int64_t)o[q] * kpad + koff) : zero4<T>();
+                sv[q] = EXT ? p.scale_other[o[q]] : (T)1;
+            }
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
                 if (tt + q < n) {
@@ -114,12 +133,13 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
                     d = fma(b[q].v[2], self.v[2], d);
                     d = fma(b[q].v[3], self.v[3], d);
                     d = group_sum<LPR>(d);
-                    d = vmax(d, (T)PMF_RATE_FLOOR);
+                    if (!EXT) d = vmax(d, (T)PMF_RATE_FLOOR);
                     const T w = xv[q] / d;
+                    if (EXT) xsum += xv[q];
 #pragma unroll
                     for (int e = 0; e < PMF_VEC; ++e) {
                         acc_a.v[e] += (w * b[q].v[e]) * self.v[e];
-                        acc_b.v[e] += b[q].v[e];
+                        acc_b.v[e] += EXT ? b[q].v[e] * sv[q] : b[q].v[e];
                     }
                 }
             }
@@ -127,11 +147,12 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
     }
 
     if (t.slot >= 0) {
+        T *slot = p.partial + (int64_t)t.slot * p.pw;
         if (active) {
-            T *dst = p.partial + (int64_t)t.slot * 2 * kpad + koff;
-            store4(dst, acc_a);
-            store4(dst + kpad, acc_b);
+            store4(slot + koff, acc_a);
+            store4(slot + kpad + koff, acc_b);
         }
+        if (EXT && c == 0) slot[2 * kpad] = xsum;
     } else if (STATS) {
         if (active) {
             T *dst = p.stats + (int64_t)t.row * 2 * kpad + koff;
@@ -139,14 +160,14 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
             store4(dst + kpad, acc_b);
         }
     } else {
-        gamma_finalize_row<T, LPR>(p, t.row, c, active, acc_a, acc_b);
+        gamma_finalize_row<T, LPR, EXT>(p, t.row, c, active, acc_a, acc_b, xsum, t.len == 0);
     }
 }
 
 // One block per split row: group g adds slots g, g+G, ... in order, the G
 // group sums are then added in group order by group 0 (fixed order => bitwise
 // reproducible), which finalises the row (or writes its raw sums in STATS mode).
-template <typename T, int LPR, bool STATS>
+template <typename T, int LPR, bool STATS, bool EXT>
 __global__ __launch_bounds__(256) void gamma_split_kernel(GammaParams<T> p) {
     constexpr int G = 256 / LPR;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -158,9 +179,12 @@ __global__ __launch_bounds__(256) void gamma_split_kernel(GammaParams<T> p) {
     const int kpad = p.kpad;
     const bool active = koff < kpad;
     Vec4<T> sa = zero4<T>(), sb = zero4<T>();
+    T xsum = (T)0;
+    if (EXT && threadIdx.x == 0)  // G*2*kpad sums are staged in LDS; sum x is tiny: one lane adds it in order
+        for (int s = 0; s < sr.n_slots; ++s) xsum += p.partial[(int64_t)(sr.first_slot + s) * p.pw + 2 * kpad];
     if (active) {
         for (int s = g; s < sr.n_slots; s += G) {
-            const T *src = p.partial + (int64_t)(sr.first_slot + s) * 2 * kpad + koff;
+            const T *src = p.partial + (int64_t)(sr.first_slot + s) * p.pw + koff;
             Vec4<T> a = load4(src), b = load4(src + kpad);
 #pragma unroll
             for (int e = 0; e < PMF_VEC; ++e) {
@@ -194,7 +218,8 @@ __global__ __launch_bounds__(256) void gamma_split_kernel(GammaParams<T> p) {
             store4(dst + kpad, sb);
         }
     } else {
-        gamma_finalize_row<T, LPR>(p, sr.row, c, active, sa, sb);
+        if (EXT) xsum = __shfl(xsum, 0, LPR);  // group 0 = lanes [0, LPR): lane 0 holds the total
+        gamma_finalize_row<T, LPR, EXT>(p, sr.row, c, active, sa, sb, xsum, false);
     }
 }
 
@@ -213,32 +238,36 @@ __global__ __launch_bounds__(256) void gamma_finalize_all_kernel(GammaParams<T> 
         sa = load4(src);
         sb = load4(src + p.kpad);
     }
-    gamma_finalize_row<T, LPR>(p, (int)row, c, active, sa, sb);
+    gamma_finalize_row<T, LPR, false>(p, (int)row, c, active, sa, sb, (T)0, false);
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 template <typename T, int LPR>
-static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, int mode /*0 fused, 1 accumulate, 2 finalize*/) {
+static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, int mode /*0 fused, 1 accumulate, 2 finalize, 3 extended*/) {
     constexpr int G = 256 / LPR;
     const PmfTaskList &tl = ctx->index[side].gamma_tasks;
-    if (mode == 0 || mode == 1) {
+    if (mode != 2) {
         if (tl.n_tasks > 0) {
             PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_SWEEP);
             dim3 grid((unsigned)((tl.n_tasks + G - 1) / G));
             if (mode == 0)
-                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, false>), grid, dim3(256), 0, ctx->stream, p);
+                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, false, false>), grid, dim3(256), 0, ctx->stream, p);
+            else if (mode == 3)
+                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, false, true>), grid, dim3(256), 0, ctx->stream, p);
             else
-                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, true>), grid, dim3(256), 0, ctx->stream, p);
+                hipLaunchKernelGGL((gamma_sweep_kernel<T, LPR, true, false>), grid, dim3(256), 0, ctx->stream, p);
         }
         if (tl.n_split > 0) {
             PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_FINAL);
             size_t smem = (size_t)G * 2 * ctx->kpad * sizeof(T);
             if (mode == 0)
-                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, false>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
+                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, false, false>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
+            else if (mode == 3)
+                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, false, true>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
             else
-                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, true>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
+                hipLaunchKernelGGL((gamma_split_kernel<T, LPR, true, false>), dim3((unsigned)tl.n_split), dim3(256), smem, ctx->stream, p);
         }
     } else {
         PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_FINAL);
@@ -267,8 +296,15 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
             if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_HYPER_RATE))) return rc;
         }
     }
+    const int pw = 2 * ctx->kpad + (mode == 3 ? PMF_VEC : 0);
     if (mode != 2 && tl.n_slots > 0)
-        if ((rc = pmf_ensure_partial(ctx, (size_t)tl.n_slots * 2 * ctx->kpad * sizeof(T)))) return rc;
+        if ((rc = pmf_ensure_partial(ctx, (size_t)tl.n_slots * pw * sizeof(T)))) return rc;
+    if (mode == 3) {
+        if ((rc = pmf_require_array(ctx, side, PMF_ARR_SCALE, "pmf_gamma_ext_sweep"))) return rc;
+        if ((rc = pmf_require_array(ctx, other, PMF_ARR_SCALE, "pmf_gamma_ext_sweep"))) return rc;
+        if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_SCALE_SHAPE))) return rc;
+        if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_SCALE_RATE))) return rc;
+    }
 
     GammaParams<T> p;
     p.tasks = tl.d_tasks;
@@ -282,6 +318,11 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
     p.rate = (T *)ctx->arr[side][PMF_ARR_RATE];
     p.prior_rate_vec = (T *)ctx->arr[side][PMF_ARR_PRIOR_RATE];
     p.hyper_rate = (T *)ctx->arr[side][PMF_ARR_HYPER_RATE];
+    p.scale_other = (const T *)ctx->arr[other][PMF_ARR_SCALE];
+    p.scale_self = (T *)ctx->arr[side][PMF_ARR_SCALE];
+    p.scale_shape = (T *)ctx->arr[side][PMF_ARR_SCALE_SHAPE];
+    p.scale_rate = (T *)ctx->arr[side][PMF_ARR_SCALE_RATE];
+    p.pw = pw;
     p.partial = (T *)ctx->d_partial;
     p.stats = (T *)stats;
     p.shape_prior = (T)shape_prior;
@@ -317,6 +358,12 @@ extern "C" int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, doubl
     if (ctx->dtype == PMF_F64)
         return run_gamma<double>(ctx, side, 0, nullptr, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
     return run_gamma<float>(ctx, side, 0, nullptr, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+}
+
+extern "C" int pmf_gamma_ext_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior) {
+    GAMMA_PROLOGUE("pmf_gamma_ext_sweep");
+    if (ctx->dtype == PMF_F64) return run_gamma<double>(ctx, side, 3, nullptr, shape_prior, rate_prior, 0, 0, 0);
+    return run_gamma<float>(ctx, side, 3, nullptr, shape_prior, rate_prior, 0, 0, 0);
 }
 
 extern "C" int pmf_gamma_accumulate(pmf_ctx *ctx, int side, void *stats_dev) {

@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "libpmf_hip.so")
 
 F32, F64 = 0, 1
 USER, ITEM = 0, 1
-ARR_FACTOR, ARR_SHAPE, ARR_RATE, ARR_PRIOR_RATE, ARR_HYPER_RATE, ARR_COV, ARR_BIAS = range(7)
+(ARR_FACTOR, ARR_SHAPE, ARR_RATE, ARR_PRIOR_RATE, ARR_HYPER_RATE, ARR_COV, ARR_BIAS, ARR_SCALE, ARR_SCALE_SHAPE,
+ ARR_SCALE_RATE) = range(10)
+PREDICT_BIAS, PREDICT_SCALE = 1, 2
 KERNEL_NAMES = ("gamma_sweep", "gamma_final", "gauss_accum", "gauss_solve", "gauss_bias",
                 "eval", "predict", "topk", "gauss_combine")
 MAX_LABELS = 32
@@ -50,6 +52,7 @@ SIGNATURES = {
     "pmf_get_array": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
     "pmf_set_cov_identity": (C.c_int, [_p, C.c_int, C.c_double]),
     "pmf_gamma_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
+    "pmf_gamma_ext_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double]),
     "pmf_ctx_kpad": (C.c_int, [_p, C.POINTER(C.c_int)]),
     "pmf_gamma_accumulate": (C.c_int, [_p, C.c_int, _p]),
     "pmf_gamma_finalize": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),

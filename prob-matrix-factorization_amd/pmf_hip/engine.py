@@ -101,6 +101,10 @@ class Context:
                                         int(bool(hierarchical)), float(hyper_shape),
                                         float(hyper_rate_prior)), "pmf_gamma_sweep")
 
+    def gamma_ext_sweep(self, side, shape_prior, rate_prior):
+        check(self._lib.pmf_gamma_ext_sweep(self._h, side, float(shape_prior), float(rate_prior)),
+              "pmf_gamma_ext_sweep")
+
     def gamma_accumulate(self, side, stats_ptr):
         check(self._lib.pmf_gamma_accumulate(self._h, side, C.c_void_p(stats_ptr)), "pmf_gamma_accumulate")
 
@@ -152,7 +156,7 @@ class Context:
         out = np.zeros(len(u), dtype=np.float64)
         if len(u):
             check(self._lib.pmf_predict(self._h, len(u), ptr(u, C.c_int32), ptr(i, C.c_int32),
-                                        int(bool(use_bias)), float(offset), ptr(out, C.c_double)),
+                                        int(use_bias), float(offset), ptr(out, C.c_double)),
                   "pmf_predict")
         return out
 
@@ -177,7 +181,7 @@ class Context:
         sse = C.c_double(0.0)
         abs_l = np.zeros(MAX_LABELS, dtype=np.float64)
         cnt_l = np.zeros(MAX_LABELS, dtype=np.int64)
-        check(self._lib.pmf_eval_run(self._h, int(bool(use_bias)), float(offset), C.byref(sse),
+        check(self._lib.pmf_eval_run(self._h, int(use_bias), float(offset), C.byref(sse),
                                      ptr(abs_l, C.c_double), ptr(cnt_l, C.c_int64)), "pmf_eval_run")
         L = self._eval_labels
         rmse = float(np.sqrt(sse.value / self._eval_n))

@@ -37,6 +37,8 @@ from src.models.gaussian_mf_cavi import GaussianMFCAVIConfig as RefGaussCfg  # n
 from src.models.poisson_mf_cavi import PoissonMFCAVI as RefPoisson  # noqa: E402
 from src.models.poisson_mf_cavi import PoissonMFCAVIConfig as RefPoissonCfg  # noqa: E402
 from src.models.hpf_cavi import HPF_CAVI as RefHPF, HPF_CAVI_Config as RefHPFCfg  # noqa: E402
+from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVI as RefExt  # noqa: E402
+from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVIConfig as RefExtCfg  # noqa: E402
 from src.evaluation import metrics as ref_metrics  # noqa: E402
 
 
@@ -99,6 +101,9 @@ def state_of(model, kind):
         return {"a_theta": model.a_theta, "b_theta": model.b_theta,
                 "a_beta": model.a_beta, "b_beta": model.b_beta,
                 "E_theta": model.E_theta, "E_beta": model.E_beta}
+    if kind == "poisson_ext":
+        return {k: getattr(model, k) for k in ("a_theta", "b_theta", "a_beta", "b_beta", "a_phi", "b_phi",
+                                               "a_psi", "b_psi", "E_theta", "E_beta", "E_phi", "E_psi")}
     if kind == "hpf":
         return {"gamma_a_theta": model.gamma_a_theta, "gamma_b_theta": model.gamma_b_theta,
                 "gamma_a_beta": model.gamma_a_beta, "gamma_b_beta": model.gamma_b_beta,
@@ -119,6 +124,8 @@ def make(kind, cfg_kwargs):
         return RefPoisson(RefPoissonCfg(**cfg_kwargs))
     if kind == "hpf":
         return RefHPF(RefHPFCfg(**cfg_kwargs))
+    if kind == "poisson_ext":
+        return RefExt(RefExtCfg(**cfg_kwargs))
     raise ValueError(kind)
 
 
@@ -142,9 +149,10 @@ BASE_CFG = {
     "gauss": dict(sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5),
     "poisson": dict(a0=0.1, b0=0.5),
     "hpf": dict(a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0),
+    "poisson_ext": dict(a0=0.3, b0=1.0),
 }
 # tolerances chosen so that the early-stop rule of each model fires mid-run
-STOP_TOL = {"gauss_bias": 2e-3, "gauss": 2e-3, "poisson": 2e-3, "hpf": 2e-3}
+STOP_TOL = {"gauss_bias": 2e-3, "gauss": 2e-3, "poisson": 2e-3, "hpf": 2e-3, "poisson_ext": 2e-3}
 
 
 def gen_model_case(kind, seed, K):
@@ -185,7 +193,8 @@ def gen_model_case(kind, seed, K):
             else:
                 out["it3_predict"] = m.predict(PRED_U, PRED_I)
                 out["it3_val_rmse"] = np.float64(m.evaluate_rmse(val))
-                out["it3_val_macro_mae"] = np.float64(m.evaluate_macro_mae(val))
+                if hasattr(m, "evaluate_macro_mae"):
+                    out["it3_val_macro_mae"] = np.float64(m.evaluate_macro_mae(val))
     # validation trajectory + early stop (full-precision values re-derived by
     # re-running fit with max_iter = t; the printed ones have 4 decimals)
     cfg = dict(base, max_iter=40, tol=STOP_TOL[kind], verbose=True)
@@ -206,7 +215,7 @@ def gen_model_case(kind, seed, K):
         else:
             mt.fit(train)
             traj_rmse.append(mt.evaluate_rmse(val))
-            traj_mae.append(mt.evaluate_macro_mae(val))
+            traj_mae.append(mt.evaluate_macro_mae(val) if hasattr(mt, "evaluate_macro_mae") else np.nan)
     out["stop_val_rmse"] = np.array(traj_rmse)
     out["stop_val_macro_mae"] = np.array(traj_mae)
     out["stop_iterations_run"] = np.int64(n_done)
@@ -301,11 +310,16 @@ def gen_hpf_torch():
 
 
 def main():
-    for kind in ("hpf", "poisson", "gauss_bias", "gauss"):
+    only = sys.argv[1:]
+    for kind in ("hpf", "poisson", "gauss_bias", "gauss", "poisson_ext"):
+        if only and kind not in only:
+            continue
         for seed, K in ((42, 8), (7, 16)):
             path = os.path.join(OUT, f"{kind}_s{seed}_k{K}.npz")
             np.savez_compressed(path, **gen_model_case(kind, seed, K))
             print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+    if only:
+        return
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **gen_metrics())
     np.savez_compressed(os.path.join(OUT, "medium_c1.npz"), **gen_medium())
     np.savez_compressed(os.path.join(OUT, "hpf_torch.npz"), **gen_hpf_torch())

@@ -126,6 +126,60 @@ def test_poisson_rate_floor_and_zero_ratings(dtype):
         assert rel_err(ctx.get_array(USER, ARR_FACTOR), a / b) <= tol
 
 
+EXT_KEYS = ["a_theta", "b_theta", "a_beta", "b_beta", "a_phi", "b_phi", "a_psi", "b_psi",
+            "E_theta", "E_beta", "E_phi", "E_psi"]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["poisson_ext_s42_k8", "poisson_ext_s7_k16"])
+def test_extended_poisson_matches_reference_goldens(case, dtype):
+    from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVI, PoissonMFExtendedCAVIConfig
+    d, meta = load_case(case)
+    train, val = frames(d)
+    kw = dict(meta["base_cfg"], n_factors=meta["K"], random_state=meta["seed"], verbose=False)
+    for n_it in (0, 1, 3, 20):
+        m = PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(max_iter=n_it, tol=None, **kw), dtype=dtype).fit(train)
+        for key in EXT_KEYS:
+            tol = 1e-15 if n_it == 0 else TOL[dtype][n_it] * (10 if dtype == "f64" else 4)
+            assert rel_err(getattr(m, key), d[f"it{n_it}_{key}"]) <= tol, (key, n_it)
+        if n_it == 3:
+            ptol = 1e-10 if dtype == "f64" else 2e-4
+            np.testing.assert_allclose(m.predict(d["pred_u"], d["pred_i"]), d["it3_predict"], rtol=ptol, atol=1e-12)
+            np.testing.assert_allclose(m.evaluate_rmse(val), float(d["it3_val_rmse"]), rtol=ptol)
+        m.close()
+    m = PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(max_iter=40, tol=meta["stop_tol"], **kw),
+                              dtype=dtype).fit(train, val_df=val)
+    assert m.history_["iterations"] == int(d["stop_iterations_run"]) and m.history_["stopped_early"] == bool(d["stop_early"])
+    np.testing.assert_allclose(m.history_["val_rmse"], d["stop_val_rmse"], rtol=1e-9 if dtype == "f64" else 2e-4)
+
+
+def test_extended_poisson_split_rows_vs_oracle():
+    """Heavy rows (several chunks) and empty rows through pmf_gamma_ext_sweep."""
+    import pmf_hip
+    from pmf_hip import ARR_FACTOR, ARR_RATE, ARR_SCALE, ARR_SCALE_RATE, ARR_SCALE_SHAPE, ARR_SHAPE, ITEM, USER
+    U, I, N, K = 2000, 150, 40000, 12
+    u, i, x = skewed_problem(9, U, I, N)
+    st = orc.init_poisson_ext(U, I, K, 0.3, 1.0, seed=4)
+    idx = (orc.group_positions(u, U), orc.group_positions(i, I))
+    assert np.diff(idx[1][0]).max() > 1000
+    with pmf_hip.Context(U, I, K, dtype="f64") as ctx:
+        ctx.set_ratings(u, i, x)
+        ctx.set_array(USER, ARR_FACTOR, st["E_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["E_beta"])
+        ctx.set_array(USER, ARR_SCALE, st["E_phi"]); ctx.set_array(ITEM, ARR_SCALE, st["E_psi"])
+        for _ in range(2):
+            orc.poisson_ext_iteration(st, idx, u, i, x, 0.3, 1.0)
+            ctx.gamma_ext_sweep(USER, 0.3, 1.0)
+            ctx.gamma_ext_sweep(ITEM, 0.3, 1.0)
+        got = {"a_theta": ctx.get_array(USER, ARR_SHAPE), "b_theta": ctx.get_array(USER, ARR_RATE),
+               "E_theta": ctx.get_array(USER, ARR_FACTOR), "E_phi": ctx.get_array(USER, ARR_SCALE),
+               "a_phi": ctx.get_array(USER, ARR_SCALE_SHAPE), "b_phi": ctx.get_array(USER, ARR_SCALE_RATE),
+               "a_beta": ctx.get_array(ITEM, ARR_SHAPE), "b_beta": ctx.get_array(ITEM, ARR_RATE),
+               "E_beta": ctx.get_array(ITEM, ARR_FACTOR), "E_psi": ctx.get_array(ITEM, ARR_SCALE),
+               "a_psi": ctx.get_array(ITEM, ARR_SCALE_SHAPE), "b_psi": ctx.get_array(ITEM, ARR_SCALE_RATE)}
+    for key, val in got.items():
+        assert rel_err(val, st[key]) <= 1e-10, key
+
+
 def test_bad_ids_are_rejected():
     import pmf_hip
     with pmf_hip.Context(10, 10, 8) as ctx:

@@ -31,6 +31,8 @@ STATE_KEYS = {
             "gamma_b_eta", "E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_xi", "gamma_a_eta"],
     "gauss_bias": ["m_theta", "m_beta", "m_user_bias", "m_item_bias"],
     "gauss": ["m_theta", "m_beta"],
+    "poisson_ext": ["a_theta", "b_theta", "a_beta", "b_beta", "a_phi", "b_phi", "a_psi", "b_psi",
+                    "E_theta", "E_beta", "E_phi", "E_psi"],
 }
 
 
@@ -41,7 +43,9 @@ def test_states_after_n_iterations(path, vectorised):
     kind = meta["kind"]
     tr = (d["train_u"], d["train_i"], d["train_rating"])
     for n_it in meta["iters"]:
-        st, hist = orc.fit(kind, *tr, _cfg(meta, n_it, None if kind in ("poisson", "hpf") else 0.0),
+        if kind == "poisson_ext" and vectorised:
+            pytest.skip("the extended model has a per-row form only")
+        st, hist = orc.fit(kind, *tr, _cfg(meta, n_it, 0.0 if kind.startswith("gauss") else None),
                            global_mean=float(d["global_mean"]), vectorised=vectorised)
         assert hist["iterations"] == n_it
         for key in STATE_KEYS[kind]:
@@ -61,6 +65,9 @@ def test_states_after_n_iterations(path, vectorised):
                                     float(d["global_mean"]))
                 r, mm = orc.gaussian_eval(st, d["val_u"], d["val_i"], d["val_rating"],
                                           float(d["global_mean"]), bias=bias)
+            elif kind == "poisson_ext":
+                p = orc.ext_predict(st, d["pred_u"], d["pred_i"])
+                r, mm = orc.rmse(d["val_rating"], orc.ext_predict(st, d["val_u"], d["val_i"])), None
             else:
                 p = orc.predict_dot(st["E_theta"], st["E_beta"], d["pred_u"], d["pred_i"])
                 r, mm = orc.gamma_eval(st, d["val_u"], d["val_i"], d["val_rating"])
@@ -77,11 +84,11 @@ def test_validation_trajectory_and_early_stop(path):
     st, hist = orc.fit(kind, d["train_u"], d["train_i"], d["train_rating"],
                        _cfg(meta, 40, meta["stop_tol"]),
                        val=(d["val_u"], d["val_i"], d["val_rating"]),
-                       global_mean=float(d["global_mean"]), vectorised=True)
+                       global_mean=float(d["global_mean"]), vectorised=(kind != "poisson_ext"))
     assert hist["iterations"] == int(d["stop_iterations_run"])
     assert hist["stopped_early"] == bool(d["stop_early"])
     np.testing.assert_allclose(hist["val_rmse"], d["stop_val_rmse"], rtol=1e-10)
-    if kind != "gauss":
+    if kind not in ("gauss", "poisson_ext"):
         np.testing.assert_allclose(hist["val_macro_mae"], d["stop_val_macro_mae"], rtol=1e-10)
     for key in STATE_KEYS[kind]:
         np.testing.assert_allclose(st[key], d[f"stop_{key}"], rtol=1e-9, atol=1e-12)

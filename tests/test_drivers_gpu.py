@@ -102,3 +102,33 @@ def test_config5_poisson_k64_rmse_parity_with_cpu_oracle(workdir):
         kth = b[tb[-1]]
         same += set(ta) == set(tb) or all(abs(b[j] - kth) <= 1e-5 * abs(kth) or j in tb for j in ta)
     assert same >= 297
+
+
+def test_tune_all_models_concurrent_trials_write_a_loadable_file(workdir, monkeypatch, capsys):
+    """Random search with 4 concurrent engine contexts; the file it writes must
+    round-trip through load_best_hyperparams into the config dataclasses."""
+    import shutil
+    from src.experiments import tune_all_models
+    from src.experiments.compare_models import load_best_hyperparams
+    from src.models.gaussian_mf_cavi_bias import GaussianMFCAVIConfig
+    from src.models.hpf_cavi import HPF_CAVI_Config
+    from src.models.poisson_mf_cavi import PoissonMFCAVIConfig
+    monkeypatch.chdir(workdir)
+    shutil.copy("best_hyperparams.txt", "best_hyperparams.keep")
+    try:
+        monkeypatch.setattr("sys.argv", ["tune_all_models", "--n_trials", "4", "--workers", "4", "--seed", "3"])
+        monkeypatch.setattr(tune_all_models, "tune_hpf_pytorch", lambda *a, **k: None)   # covered elsewhere; slow
+        tune_all_models.main()
+        out = capsys.readouterr().out
+        assert "failed" not in out and out.count("Trial ") == 12, out[-2000:]
+        got = load_best_hyperparams("best_hyperparams.txt")
+        assert set(got) == {"GaussianMF", "PoissonMF", "HPF_CAVI"}
+        GaussianMFCAVIConfig(**got["GaussianMF"]); PoissonMFCAVIConfig(**got["PoissonMF"]); HPF_CAVI_Config(**got["HPF_CAVI"])
+        assert got["GaussianMF"]["n_factors"] in (30, 50, 70) and got["HPF_CAVI"]["a"] == got["HPF_CAVI"]["c"]
+        # the same seed draws the same configurations regardless of the worker count
+        first = open("best_hyperparams.txt").read()
+        monkeypatch.setattr("sys.argv", ["tune_all_models", "--n_trials", "4", "--workers", "1", "--seed", "3"])
+        tune_all_models.main()
+        assert open("best_hyperparams.txt").read() == first
+    finally:
+        shutil.move("best_hyperparams.keep", "best_hyperparams.txt")

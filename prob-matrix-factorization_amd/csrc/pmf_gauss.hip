@@ -248,6 +248,109 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
                             p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, lane);
 }
 
+// 64 < K <= 128, fp32: the same sweep with two columns per lane (j0 = lane,
+// j1 = lane + 64) and 128 row registers per column set -- 256 VGPRs of matrix,
+// one wavefront per SIMD.  The pivot loop is split at 64 so that the register
+// the pivot column is read from stays a compile-time choice.
+__device__ __forceinline__ void solve_from_image_wide(const float *img, float w0, float w1, int K, int kpad,
+                                                      float inv_sigma2, float inv_eta2, float *vout, float *mout,
+                                                      int lane) {
+    constexpr int KR = 128;
+    float B0[KR], B1[KR];
+    const int j0 = lane, j1 = lane + 64;
+    const int j0c = j0 < K ? j0 : 0, j1c = j1 < K ? j1 : 0;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const int ic = i < K ? i : 0;
+        int lo = ic < j0c ? ic : j0c, hi = ic < j0c ? j0c : ic;
+        float s0 = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
+        lo = ic < j1c ? ic : j1c;
+        hi = ic < j1c ? j1c : ic;
+        float s1 = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
+        if (!(i < K && j0 < K)) s0 = 0.f;
+        if (!(i < K && j1 < K)) s1 = 0.f;
+        if (i == j0) s0 += (i < K) ? inv_eta2 : 1.f;
+        if (i == j1) s1 += (i < K) ? inv_eta2 : 1.f;
+        B0[i] = s0;
+        B1[i] = s1;
+    }
+    float d0 = 1.f, d1 = 1.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const float a = readlane_dyn(B0[i], i), b = readlane_dyn(B1[i + 64], i);
+        if (lane == i) {
+            d0 = a;
+            d1 = b;
+        }
+    }
+    const float g0 = 1.f / sqrtf(d0), g1 = 1.f / sqrtf(d1);
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const float gi = i < 64 ? readlane_dyn(g0, i) : readlane_dyn(g1, i - 64);
+        B0[i] = B0[i] * g0 * gi;
+        B1[i] = B1[i] * g1 * gi;
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+        for (int kk = 0; kk < 64; ++kk) {
+            const float v0 = B0[0], v1 = B1[0];
+            const float piv = half == 0 ? readlane_dyn(v0, kk) : readlane_dyn(v1, kk);
+            const float pinv = 1.f / piv;
+            const float u0 = v0 * pinv, u1 = v1 * pinv;
+            const bool at0 = (half == 0) && (lane == kk), at1 = (half == 1) && (lane == kk);
+            const float uc0 = at0 ? (1.f - pinv) : u0, uc1 = at1 ? (1.f - pinv) : u1;
+#pragma unroll
+            for (int i0 = 1; i0 < KR; i0 += 32) {
+                float sc[32];
+#pragma unroll
+                for (int q = 0; q < 32; ++q)
+                    if (i0 + q < KR)
+                        sc[q] = half == 0 ? readlane_dyn(B0[i0 + q], kk) : readlane_dyn(B1[i0 + q], kk);
+#pragma unroll
+                for (int q = 0; q < 32; ++q)
+                    if (i0 + q < KR) {
+                        B0[i0 + q - 1] = fmaf(-sc[q], uc0, B0[i0 + q]);
+                        B1[i0 + q - 1] = fmaf(-sc[q], uc1, B1[i0 + q]);
+                    }
+            }
+            B0[KR - 1] = at0 ? -pinv : u0;
+            B1[KR - 1] = at1 ? -pinv : u1;
+        }
+    }
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const float gi = i < 64 ? readlane_dyn(g0, i) : readlane_dyn(g1, i - 64);
+        const float wi = i < 64 ? readlane_dyn(w0, i) : readlane_dyn(w1, i - 64);
+        const float a = -B0[i] * g0 * gi, b = -B1[i] * g1 * gi;
+        m0 = fmaf(a, wi, m0);
+        m1 = fmaf(b, wi, m1);
+        if (i < K) {
+            if (j0 <= i) vout[i * (i + 1) / 2 + j0] = a;
+            if (j1 <= i) vout[i * (i + 1) / 2 + j1] = b;
+        }
+    }
+    if (j0 < kpad) mout[j0] = (j0 < K) ? m0 * inv_sigma2 : 0.f;
+    if (j1 < kpad) mout[j1] = (j1 < K) ? m1 * inv_sigma2 : 0.f;
+}
+
+__global__ __launch_bounds__(64) void gauss_solve_wide_kernel(SolveParams<float> p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int64_t idx = blockIdx.x;
+    const int row = p.rows ? rfl(p.rows[idx]) : (int)idx;
+    const float *S = p.src_s + (int64_t)row * p.src_s_stride;
+    if (!p.rows && S[0] == 0.f) return;
+    float *img = reinterpret_cast<float *>(smem_raw);
+    for (int q = lane * PMF_VEC; q < p.cov_stride; q += 64 * PMF_VEC) store4(img + q, load4(S + q));
+    wave_lds_fence();
+    const float *w = p.src_w + (int64_t)row * p.src_w_stride;
+    const float w0 = lane < p.K ? w[lane] : 0.f, w1 = lane + 64 < p.K ? w[lane + 64] : 0.f;
+    solve_from_image_wide(img, w0, w1, p.K, p.kpad, p.inv_sigma2, p.inv_eta2,
+                          p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, lane);
+}
+
 // ---------------------------------------------------------------------------
 // accumulate, K = 64 fp32: covariance rows on the VALU, m m^T on the MFMA pipe
 // ---------------------------------------------------------------------------
@@ -733,7 +836,11 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (ctx->K <= 16) launch_solve_reg<T, 16>(ctx, sp);
     else if (ctx->K <= 32) launch_solve_reg<T, 32>(ctx, sp);
     else if (ctx->K <= 64) launch_solve_reg<T, 64>(ctx, sp);
-    else {
+    else if (std::is_same<T, float>::value && !getenv("PMF_GAUSS_LDS_SOLVE")) {
+        if constexpr (std::is_same<T, float>::value)
+            hipLaunchKernelGGL(gauss_solve_wide_kernel, dim3((unsigned)sp.n), dim3(64),
+                               (size_t)ctx->cov_stride * sizeof(float), ctx->stream, sp);
+    } else {
         const int K = ctx->K;
         size_t smem = ((size_t)K * (K + 1) + 3 * K) * sizeof(T);
         hipError_t e = hipFuncSetAttribute((const void *)gauss_solve_lds_kernel<T>,

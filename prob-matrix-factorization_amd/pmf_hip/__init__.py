@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -85,6 +86,14 @@ def load():
             f"{LIB_PATH} not found: the HIP engine has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` from the repository root. "
             "There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  If /opt/rocm's libamdhip64 (this
+    # library's dependency) is mapped first, a later `import torch` ends up with two runtimes and
+    # silently reports no GPU.  Loading torch first makes both share torch's copy.
+    if "torch" not in sys.modules and os.environ.get("PMF_HIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # missing libamdhip64 etc.

@@ -132,3 +132,15 @@ def test_tune_all_models_concurrent_trials_write_a_loadable_file(workdir, monkey
         assert open("best_hyperparams.txt").read() == first
     finally:
         shutil.move("best_hyperparams.keep", "best_hyperparams.txt")
+
+
+def test_engine_first_then_torch_still_sees_the_gpu():
+    """Load order regression: torch bundles its own HIP runtime; the binding must
+    not leave the process in a state where torch.cuda is unavailable."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import pmf_hip; c = pmf_hip.Context(4, 4, 4); c.close(); "
+            "import torch; assert torch.cuda.is_available(); print('ok')") % os.path.join(
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prob-matrix-factorization_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

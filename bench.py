@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a single-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0")
+    ap.add_argument("--factors", type=int, default=None, help="exploration: override the workload's K")
     args = ap.parse_args()
 
     import torch
@@ -148,6 +149,9 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.small:
         w.update(SMALL)
+    if args.factors:
+        w["K"] = args.factors
+        w["label"] += f" [K overridden to {args.factors}]"
     U, I, N, K, hp = w["U"], w["I"], w["N"], w["K"], w["hp"]
 
     # ---- data + state (untimed) ------------------------------------------

@@ -352,93 +352,114 @@ __global__ __launch_bounds__(64) void gauss_solve_wide_kernel(SolveParams<float>
 }
 
 // ---------------------------------------------------------------------------
-// accumulate, K = 64 fp32: covariance rows on the VALU, m m^T on the MFMA pipe
+// accumulate (+ fused solve), fp32, K <= 64: covariance rows on the VALU, m m^T on
+// the MFMA pipe
 // ---------------------------------------------------------------------------
-// Packed row length 2080 floats = 520 16-byte chunks: chunk q = lane + 64 t,
-// t = 0..8 (t = 8 only lanes 0..7).  Two ratings per step feed one
-// v_mfma_f32_32x32x2_f32 (k = 2): lanes 0-31 carry rating j, lanes 32-63 rating
-// j+1; the three lower 32x32 blocks of the 64x64 outer-product sum live in 48
-// accumulator registers and are folded into the packed image through LDS once
-// per task.
-#define G64_KP 2080
-#define G64_CHUNKS 520
-#define G64_T 9
-
-template <bool FUSE>
-__global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<float> p, float inv_sigma2,
-                                                                float inv_eta2, float *cov_self, float *factor_self) {
-    __shared__ __align__(16) float lds[4][G64_KP];
+// KB = 32 (K <= 32: one 32x32 block) or 64 (the three lower 32x32 blocks).  The
+// packed row is cov_stride/4 16-byte chunks: chunk q = lane + 64 s, s < NT.  Two
+// ratings feed one v_mfma_f32_32x32x2_f32 (k = 2): lanes 0-31 carry rating j,
+// lanes 32-63 rating j+1 (operand lanes >= K hold zeros, so K need not be a
+// multiple of 32; storage stays the exact K(K+1)/2 packing).  PU pairs are in
+// flight per loop trip so that short rows (small K) still keep ~18 16-byte loads
+// per lane outstanding.  The MFMA blocks are folded into the packed image through
+// LDS once per task; a task that is a whole row is solved on the spot (FUSE).
+template <int KB, int NT, bool FUSE>
+__global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel(GaussParams<float> p, float inv_sigma2,
+                                                                                float inv_eta2, float *cov_self,
+                                                                                float *factor_self) {
+    constexpr int NB = KB == 64 ? 3 : 1;
+    constexpr int PU = NT >= 5 ? 1 : (NT >= 3 ? 2 : (NT == 2 ? 4 : 8));
+    extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
     if (task_id >= p.n_tasks) return;
     const PmfTask t = load_task_uniform(p.tasks, task_id);
     const int h = lane >> 5, c = lane & 31;
+    const int K = p.K, kpad = p.kpad, stride = p.cov_stride, chunks = p.cov_stride / PMF_VEC;
     const int32_t *col = p.other + t.start;
     const float *val = p.val + t.start;
     const float b_self = p.bias_self ? p.bias_self[t.row] : 0.f;
+    const bool lo_ok = c < K, hi_ok = (KB == 64) && (32 + c < K);
 
-    f32x16 d00, d10, d11;
+    f32x16 d[NB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        d00[r] = 0.f;
-        d10[r] = 0.f;
-        d11[r] = 0.f;
-    }
-    float4 acc[G64_T];
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int s = 0; s < G64_T; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < 16; ++r) d[b][r] = 0.f;
+    float4 acc[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     float wlo = 0.f, whi = 0.f;
 
-    for (int j = 0; j < t.len; j += 2) {
-        const bool two = (j + 1) < t.len;
-        const int o0 = col[j];
-        const int o1 = two ? col[j + 1] : o0;
-        const int oh = h ? o1 : o0;
-        const bool live = (h == 0) || two;
-        const float *mrow = p.factor_other + (int64_t)oh * 64;
-        float mlo = mrow[c], mhi = mrow[32 + c];
-        const float xh = val[j + (live ? h : 0)];
-        const float resid = xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f);
-        if (!live) {
-            mlo = 0.f;
-            mhi = 0.f;
-        }
-        wlo = fmaf(mlo, resid, wlo);
-        whi = fmaf(mhi, resid, whi);
-        const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * G64_KP);
-        const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * G64_KP);
-        float4 a[G64_T], b[G64_T];
+    // one loop trip = PU pairs of ratings; FULL trips carry no validity tests
+    auto trip = [&](int j, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        float4 a[PU][NT], b[PU][NT];
+        float mlo[PU], mhi[PU], res[PU];
 #pragma unroll
-        for (int s = 0; s < G64_T; ++s) {
-            const int q = lane + 64 * s;
-            a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < G64_CHUNKS) {
-                a[s] = v0[q];
-                if (two) b[s] = v1[q];
+        for (int u = 0; u < PU; ++u) {
+            const int j0 = j + 2 * u;
+            const bool has0 = FULL || j0 < t.len, has1 = FULL || j0 + 1 < t.len;
+            const int o0 = has0 ? col[j0] : 0;
+            const int o1 = has1 ? col[j0 + 1] : o0;
+            const int oh = h ? o1 : o0;
+            const bool live = h ? has1 : has0;
+            const float *mrow = p.factor_other + (int64_t)oh * kpad;
+            mlo[u] = (live && lo_ok) ? mrow[c] : 0.f;
+            mhi[u] = (live && hi_ok) ? mrow[32 + c] : 0.f;
+            const float xh = live ? val[j0 + h] : 0.f;
+            res[u] = live ? xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f) : 0.f;
+            const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * stride);
+            const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * stride);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                const int q = lane + 64 * s;
+                a[u][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b[u][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s + 1 < NT || q < chunks) {  // only the last chunk column can run past the row
+                    if (has0) a[u][s] = v0[q];
+                    if (has1) b[u][s] = v1[q];
+                }
             }
         }
-        d00 = __builtin_amdgcn_mfma_f32_32x32x2f32(mlo, mlo, d00, 0, 0, 0);
-        d10 = __builtin_amdgcn_mfma_f32_32x32x2f32(mhi, mlo, d10, 0, 0, 0);
-        d11 = __builtin_amdgcn_mfma_f32_32x32x2f32(mhi, mhi, d11, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < G64_T; ++s) {
-            acc[s].x += a[s].x + b[s].x;
-            acc[s].y += a[s].y + b[s].y;
-            acc[s].z += a[s].z + b[s].z;
-            acc[s].w += a[s].w + b[s].w;
+        for (int u = 0; u < PU; ++u) {
+            wlo = fmaf(mlo[u], res[u], wlo);
+            whi = fmaf(mhi[u], res[u], whi);
+            d[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(mlo[u], mlo[u], d[0], 0, 0, 0);
+            if constexpr (KB == 64) {
+                d[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(mhi[u], mlo[u], d[1], 0, 0, 0);
+                d[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(mhi[u], mhi[u], d[2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                acc[s].x += a[u][s].x + b[u][s].x;
+                acc[s].y += a[u][s].y + b[u][s].y;
+                acc[s].z += a[u][s].z + b[u][s].z;
+                acc[s].w += a[u][s].w + b[u][s].w;
+            }
         }
-    }
+    };
+    int j = 0;
+    for (; j + 2 * PU <= t.len; j += 2 * PU) trip(j, std::true_type{});
+    if (j < t.len) trip(j, std::false_type{});
 
     // fold the outer-product blocks into the packed image via LDS
-    float *img = lds[wave];
+    float *img = reinterpret_cast<float *>(smem_raw) + (int64_t)wave * stride;
+    // (the fold below writes every packed entry but not the row padding: clear first)
+    for (int q = lane; q < chunks; q += 64) reinterpret_cast<float4 *>(img)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of 32x32 MFMA
-        const int R1 = 32 + row;
-        if (c <= row) img[row * (row + 1) / 2 + c] = d00[r];
-        img[R1 * (R1 + 1) / 2 + c] = d10[r];
-        if (c <= row) img[R1 * (R1 + 1) / 2 + 32 + c] = d11[r];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
+        if (row < K && c <= row) img[row * (row + 1) / 2 + c] = d[0][r];
+        if constexpr (KB == 64) {
+            const int R1 = 32 + row;
+            if (R1 < K) {
+                if (c < K) img[R1 * (R1 + 1) / 2 + c] = d[1][r];
+                if (c <= row) img[R1 * (R1 + 1) / 2 + 32 + c] = d[2][r];
+            }
+        }
     }
     wave_lds_fence();
     wlo += __shfl_xor(wlo, 32, 64);
@@ -447,9 +468,9 @@ __global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<flo
         // the row is complete: finish it here (S = image + covariance sums stays in
         // LDS) while the other wavefronts of the CU keep streaming
 #pragma unroll
-        for (int s = 0; s < G64_T; ++s) {
+        for (int s = 0; s < NT; ++s) {
             const int q = lane + 64 * s;
-            if (q < G64_CHUNKS) {
+            if (q < chunks) {
                 float4 m = reinterpret_cast<float4 *>(img)[q];
                 m.x += acc[s].x;
                 m.y += acc[s].y;
@@ -459,22 +480,22 @@ __global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<flo
             }
         }
         wave_lds_fence();
-        solve_from_image<float, 64>(img, h ? whi : wlo, 64, 64, inv_sigma2, inv_eta2,
-                                    cov_self + (int64_t)t.row * G64_KP, factor_self + (int64_t)t.row * 64, lane);
+        solve_from_image<float, KB>(img, h ? whi : wlo, K, kpad, inv_sigma2, inv_eta2,
+                                    cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, lane);
         return;
     }
     float *out_s, *out_w;
     if (t.slot >= 0) {
-        out_s = p.partial + (int64_t)t.slot * (G64_KP + 64);
-        out_w = out_s + G64_KP;
+        out_s = p.partial + (int64_t)t.slot * (stride + kpad);
+        out_w = out_s + stride;
     } else {
         out_s = p.dst_s + (int64_t)t.row * p.dst_s_stride;
         out_w = p.dst_w + (int64_t)t.row * p.dst_w_stride;
     }
 #pragma unroll
-    for (int s = 0; s < G64_T; ++s) {
+    for (int s = 0; s < NT; ++s) {
         const int q = lane + 64 * s;
-        if (q < G64_CHUNKS) {
+        if (q < chunks) {
             const float4 m = reinterpret_cast<const float4 *>(img)[q];
             float4 o = acc[s];
             o.x += m.x;
@@ -485,8 +506,8 @@ __global__ __launch_bounds__(256, 2) void gauss_accum_k64_kernel(GaussParams<flo
         }
     }
     if (h == 0) {
-        out_w[c] = wlo;
-        out_w[32 + c] = whi;
+        if (c < kpad) out_w[c] = wlo;
+        if (KB == 64 && 32 + c < kpad) out_w[32 + c] = whi;
     }
 }
 
@@ -716,6 +737,40 @@ static bool use_bias(const pmf_ctx *ctx) {
 }
 
 // mode 0: fused (sums in place, then solve)   mode 1: accumulate into stats
+template <int KB, int NT>
+static void launch_accum_mfma_nt(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, bool fuse, float is2, float ie2,
+                                 float *cov, float *fac) {
+    const size_t smem = (size_t)4 * ctx->cov_stride * sizeof(float);
+    if (fuse)
+        hipLaunchKernelGGL((gauss_accum_mfma_kernel<KB, NT, true>), grid, dim3(256), smem, ctx->stream, p, is2, ie2, cov, fac);
+    else
+        hipLaunchKernelGGL((gauss_accum_mfma_kernel<KB, NT, false>), grid, dim3(256), smem, ctx->stream, p, 0.f, 0.f,
+                           (float *)nullptr, (float *)nullptr);
+}
+
+// K <= 64, fp32: pick the instantiation by MFMA block count and packed-row chunk count
+static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, bool fuse, float is2, float ie2,
+                              float *cov, float *fac) {
+    const int nt = (ctx->cov_stride / PMF_VEC + 63) / 64;  // 1..9
+    if (ctx->K <= 32) {
+        switch (nt) {
+            case 1: launch_accum_mfma_nt<32, 1>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 2: launch_accum_mfma_nt<32, 2>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            default: launch_accum_mfma_nt<32, 3>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+        }
+    } else {
+        switch (nt) {
+            case 3: launch_accum_mfma_nt<64, 3>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 4: launch_accum_mfma_nt<64, 4>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 5: launch_accum_mfma_nt<64, 5>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 6: launch_accum_mfma_nt<64, 6>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 7: launch_accum_mfma_nt<64, 7>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 8: launch_accum_mfma_nt<64, 8>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            default: launch_accum_mfma_nt<64, 9>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+        }
+    }
+}
+
 // *fused is set when the kernel also solved every single-task row (K = 64 fp32,
 // not in stats mode); the caller then only solves the split rows.
 template <typename T>
@@ -766,17 +821,12 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
         dim3 grid((unsigned)((tl.n_tasks + 3) / 4));
         bool fast = false;
         if constexpr (std::is_same<T, float>::value) {
-            if (ctx->K == 64 && !getenv("PMF_GAUSS_GENERIC")) {
+            if (ctx->K <= 64 && !getenv("PMF_GAUSS_GENERIC")) {
                 fast = true;
-                if (!stats && !getenv("PMF_GAUSS_UNFUSED")) {
-                    *fused = true;
-                    hipLaunchKernelGGL(gauss_accum_k64_kernel<true>, grid, dim3(256), 0, ctx->stream, p,
-                                       (float)(1.0 / sigma2), (float)(1.0 / eta2),
-                                       (float *)ctx->arr[side][PMF_ARR_COV], (float *)ctx->arr[side][PMF_ARR_FACTOR]);
-                } else {
-                    hipLaunchKernelGGL(gauss_accum_k64_kernel<false>, grid, dim3(256), 0, ctx->stream, p, 0.f, 0.f,
-                                       (float *)nullptr, (float *)nullptr);
-                }
+                const bool fuse = !stats && !getenv("PMF_GAUSS_UNFUSED");
+                *fused = fuse;
+                launch_accum_mfma(ctx, p, grid, fuse, (float)(1.0 / sigma2), (float)(1.0 / eta2),
+                                  (float *)ctx->arr[side][PMF_ARR_COV], (float *)ctx->arr[side][PMF_ARR_FACTOR]);
             }
         }
         if (!fast)

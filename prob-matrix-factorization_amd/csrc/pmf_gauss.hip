@@ -221,10 +221,14 @@ __device__ __forceinline__ void solve_from_image(const T *img, T wj, int K, int 
         B[KR - 1] = (j == k) ? -pinv : u;
     }
     // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
+    // (g2: an opaque copy, so the 64 per-row scale scalars are re-read here instead of
+    //  being kept alive in SGPRs across the whole sweep loop and spilled)
+    T g2 = g;
+    asm volatile("" : "+v"(g2));
     T mj = (T)0;
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
-        const T vij = -B[i] * g * readlane_dyn(g, i);
+        const T vij = -B[i] * g2 * readlane_dyn(g2, i);
         mj = fma(vij, readlane_dyn(wj, i), mj);
         if (i < K && j <= i) vout[i * (i + 1) / 2 + j] = vij;
     }

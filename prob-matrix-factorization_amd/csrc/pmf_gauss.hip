@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel
                                                                                 float inv_eta2, float *cov_self,
                                                                                 float *factor_self) {
     constexpr int NB = KB == 64 ? 3 : 1;
-    constexpr int PU = NT >= 5 ? 1 : (NT >= 3 ? 2 : (NT == 2 ? 4 : 8));
+    constexpr int PU = NT >= 5 ? 1 : (NT >= 3 ? 2 : (NT == 2 ? 4 : 8));  // PU = 2 at NT = 9 measured 1-2 % slower
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
@@ -417,13 +417,14 @@ __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel
             const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * stride);
 #pragma unroll
             for (int s = 0; s < NT; ++s) {
-                const int q = lane + 64 * s;
+                // only the last chunk column can run past the row: those lanes re-read the row's
+                // last chunk (same cache line, no extra traffic) and their sums are never stored,
+                // which keeps the whole trip free of divergent branches
+                const int q = (s + 1 < NT) ? lane + 64 * s : min(lane + 64 * s, chunks - 1);
                 a[u][s] = make_float4(0.f, 0.f, 0.f, 0.f);
                 b[u][s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s + 1 < NT || q < chunks) {  // only the last chunk column can run past the row
-                    if (has0) a[u][s] = v0[q];
-                    if (has1) b[u][s] = v1[q];
-                }
+                if (has0) a[u][s] = v0[q];
+                if (has1) b[u][s] = v1[q];
             }
         }
 #pragma unroll

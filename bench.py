@@ -67,35 +67,62 @@ def algorithmic_bytes(workload, U, I, N, K, elem=4):
     return total, total
 
 
-def cpu_baseline(workload, K, hp):
+def cpu_baseline(workload, K, hp, device=0):
     """The CPU oracle's per-row loop (the reference's loop structure) on a
-    bounded sample of the same generator: ~10-30 s of single-thread CPU work."""
+    bounded sample of the same generator: ~10-30 s of single-thread CPU work.
+    The engine then runs the same iteration on the same sample, so the line also
+    carries the second half of BASELINE.json's metric ("val RMSE vs CPU ref")."""
     from oracle import cavi_oracle as orc
-    from pmf_hip.synth import synth_ratings
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER
+    from pmf_hip.synth import synth_ratings, train_val_split
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    if workload.startswith("gaussian_mf"):
-        U, I, N = (4_000, 400, 200_000) if K <= 64 else (1_500, 150, 50_000)
+    gauss = workload.startswith("gaussian_mf")
+    if gauss:
+        U, I, N = (12_000, 1_200, 660_000) if K <= 64 else (3_000, 300, 110_000)
     else:
-        U, I, N = 100_000, 10_000, 5_000_000
+        U, I, N = 300_000, 30_000, 16_500_000
     u, i, r = synth_ratings(U, I, N, seed=7)
+    u[0], i[0] = U - 1, I - 1
+    (u, i, r), (vu, vi, vr) = train_val_split(u, i, r)
+    u[0], i[0] = U - 1, I - 1
+    N = len(u)
     u, i = u.astype(np.int64), i.astype(np.int64)
-    U, I = orc.infer_dims(u, i)
     idx = (orc.group_positions(u, U), orc.group_positions(i, I))
+    gm = float(r.mean())
+    x = r - gm if gauss else r + 1.0
+    vy = vr - gm if gauss else vr + 1.0
+    if gauss:
+        st = orc.init_gaussian(U, I, K, 0, True)
+    else:
+        st = orc.init_hpf(U, I, K, hp["a"], hp["a_prime"], hp["b_prime"], hp["c"], hp["c_prime"], hp["d_prime"], 0)
+
+    # the engine first (it needs the initial state), one iteration in fp32
+    with pmf_hip.Context(U, I, K, dtype="f32", device=device) as ctx:
+        ctx.set_ratings(u, i, x)
+        if gauss:
+            ctx.set_array(USER, ARR_FACTOR, st["m_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["m_beta"])
+            ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
+            ctx.set_array(USER, ARR_BIAS, st["m_user_bias"]); ctx.set_array(ITEM, ARR_BIAS, st["m_item_bias"])
+            ctx.gauss_factor_sweep(USER, hp["sigma2"], hp["eta_theta2"]); ctx.gauss_factor_sweep(ITEM, hp["sigma2"], hp["eta_beta2"])
+            ctx.gauss_bias_sweep(USER, hp["sigma2"], hp["eta_bias2"]); ctx.gauss_bias_sweep(ITEM, hp["sigma2"], hp["eta_bias2"])
+            pred_gpu = ctx.predict(vu, vi, use_bias=True)
+        else:
+            ctx.set_array(USER, ARR_FACTOR, st["E_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["E_beta"])
+            ctx.set_array(USER, ARR_PRIOR_RATE, st["E_xi"]); ctx.set_array(ITEM, ARR_PRIOR_RATE, st["E_eta"])
+            ctx.gamma_sweep(USER, hp["a"], 0.0, True, st["gamma_a_xi"], hp["b_prime"])
+            ctx.gamma_sweep(ITEM, hp["c"], 0.0, True, st["gamma_a_eta"], hp["d_prime"])
+            pred_gpu = ctx.predict(vu, vi)
 
     def run():
         t0 = time.perf_counter()
-        if workload.startswith("gaussian_mf"):
-            st = orc.init_gaussian(U, I, K, 0, True)
-            orc.gaussian_iteration(st, idx, u, i, r - r.mean(), hp["sigma2"], hp["eta_theta2"],
-                                   hp["eta_beta2"], hp["eta_bias2"])
+        if gauss:
+            orc.gaussian_iteration(st, idx, u, i, x, hp["sigma2"], hp["eta_theta2"], hp["eta_beta2"], hp["eta_bias2"])
         else:
-            st = orc.init_hpf(U, I, K, hp["a"], hp["a_prime"], hp["b_prime"], hp["c"], hp["c_prime"],
-                              hp["d_prime"], 0)
-            t0 = time.perf_counter()
-            orc.hpf_iteration(st, idx, u, i, r + 1.0, hp["a"], hp["b_prime"], hp["c"], hp["d_prime"])
+            orc.hpf_iteration(st, idx, u, i, x, hp["a"], hp["b_prime"], hp["c"], hp["d_prime"])
         return time.perf_counter() - t0
 
     if threadpool_limits is not None:
@@ -103,9 +130,15 @@ def cpu_baseline(workload, K, hp):
             dt = run()
     else:
         dt = run()
+    if gauss:
+        pred_cpu = orc.predict_dot(st["m_theta"], st["m_beta"], vu, vi, st["m_user_bias"], st["m_item_bias"])
+    else:
+        pred_cpu = orc.predict_dot(st["E_theta"], st["E_beta"], vu, vi)
+    rm_cpu, rm_gpu = orc.rmse(vy, pred_cpu), orc.rmse(vy, pred_gpu)
     return {"value": N / dt, "unit": "ratings/s", "cores": 1, "kind": "port",
             "sample": f"1 iteration of the oracle's per-row NumPy loop, {U}x{I}, {N} ratings, K={K} "
-                      f"(same generator), {dt:.1f} s"}
+                      f"(same generator), {dt:.1f} s",
+            "val_rmse_cpu": rm_cpu, "val_rmse_gpu_f32": rm_gpu, "val_rmse_abs_diff": abs(rm_cpu - rm_gpu)}
 
 
 def main():
@@ -265,7 +298,7 @@ def main():
         "device_GB": ctx.device_bytes() / 1e9,
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args.workload, K, hp)
+        out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank)
     print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
+#include <new>
 
 #include "pmf_internal.h"
 
@@ -333,8 +335,24 @@ static int upload_tasks(pmf_ctx *ctx, const std::vector<int64_t> &ptr, int64_t r
     return PMF_OK;
 }
 
+static int set_ratings_impl(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, const int32_t *item_ids,
+                            const double *ratings);
+
 extern "C" int pmf_ctx_set_ratings(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids,
                                    const int32_t *item_ids, const double *ratings) {
+    try {  // host containers may throw: nothing propagates across the C boundary
+        return set_ratings_impl(ctx, nnz, user_ids, item_ids, ratings);
+    } catch (const std::bad_alloc &) {
+        pmf_set_error("pmf_ctx_set_ratings: out of host memory");
+        return PMF_ENOMEM;
+    } catch (const std::exception &e) {
+        pmf_set_error("pmf_ctx_set_ratings: %s", e.what());
+        return PMF_EINVAL;
+    }
+}
+
+static int set_ratings_impl(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, const int32_t *item_ids,
+                            const double *ratings) {
     CHECK_CTX(ctx, "pmf_ctx_set_ratings");
     PMF_REQUIRE(nnz >= 0, PMF_EINVAL, "pmf_ctx_set_ratings: negative nnz");
     PMF_REQUIRE(nnz == 0 || (user_ids && item_ids && ratings), PMF_EINVAL,

@@ -46,7 +46,10 @@ class DeviceModel:
         self._dtype = engine_dtype(dtype)
         self._device = engine_device(device)
         self._ctx = None
-        self.history_ = {"val_rmse": [], "val_macro_mae": [], "iterations": 0, "stopped_early": False}
+        # structured per-iteration record next to the reference's stdout lines
+        self.history_ = {"val_rmse": [], "val_macro_mae": [], "iterations": 0, "stopped_early": False,
+                         "seconds": []}
+        self._t_last = None
 
     # ---- dimensions (hpf_cavi.py:60-64) ----------------------------------
     def _infer_dimensions(self, train_df):
@@ -61,6 +64,11 @@ class DeviceModel:
         self._ctx = pmf_hip.Context(self.n_users, self.n_items, self.config.n_factors,
                                     dtype=self._dtype, device=self._device)
         self._ctx.set_ratings(u, i, x)
+        import time
+        self._t_last = time.perf_counter()
+        for key in ("val_rmse", "val_macro_mae", "seconds"):
+            self.history_[key] = []
+        self.history_["iterations"], self.history_["stopped_early"] = 0, False
         return self._ctx
 
     def _need_ctx(self):
@@ -94,6 +102,17 @@ class DeviceModel:
             p = ctx.predict(vu, vi, self._uses_bias, offset)
             return float(rmse(y, p)), float(macro_mae(y, p))
         return slow
+
+    def _tick(self, it):
+        """Iteration `it` has been issued: count it and note the wall time since the
+        previous tick (kernels are asynchronous; with a validation monitor the tick
+        follows its synchronising read-back, so the figure is the true step time)."""
+        import time
+        now = time.perf_counter()
+        if self._t_last is not None:
+            self.history_["seconds"].append(now - self._t_last)
+        self._t_last = now
+        self.history_["iterations"] = it
 
     def _record(self, rmse_v, mae_v):
         self.history_["val_rmse"].append(rmse_v)

@@ -85,7 +85,7 @@ class GaussianHost(DeviceModel):
             if self._uses_bias:
                 ctx.gauss_bias_sweep(USER, cfg.sigma2, cfg.eta_bias2)
                 ctx.gauss_bias_sweep(ITEM, cfg.sigma2, cfg.eta_bias2)
-            self.history_["iterations"] = it
+            self._tick(it)
             if monitor is None:
                 continue
             val_rmse, val_macro_mae = monitor()

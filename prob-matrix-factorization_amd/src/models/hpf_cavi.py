@@ -90,7 +90,7 @@ class HPF_CAVI(DeviceModel):
             # theta then xi (hpf_cavi.py:126-159); beta then eta (hpf_cavi.py:162-193)
             ctx.gamma_sweep(USER, cfg.a, 0.0, True, self.gamma_a_xi, cfg.b_prime)
             ctx.gamma_sweep(ITEM, cfg.c, 0.0, True, self.gamma_a_eta, cfg.d_prime)
-            self.history_["iterations"] = it
+            self._tick(it)
             if monitor is None:
                 continue
             val_rmse, val_macro_mae = monitor()

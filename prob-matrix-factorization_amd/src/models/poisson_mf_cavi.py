@@ -66,7 +66,7 @@ class PoissonMFCAVI(DeviceModel):
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
             ctx.gamma_sweep(USER, cfg.a0, cfg.b0)   # poisson_mf_cavi.py:135-170
             ctx.gamma_sweep(ITEM, cfg.a0, cfg.b0)   # poisson_mf_cavi.py:173-200
-            self.history_["iterations"] = it
+            self._tick(it)
             if monitor is None:
                 continue
             val_rmse, val_macro_mae = monitor()

@@ -79,7 +79,7 @@ class PoissonMFExtendedCAVI(DeviceModel):
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
             ctx.gamma_ext_sweep(USER, cfg.a0, cfg.b0)   # poisson_mf_extended_cavi.py:108-160
             ctx.gamma_ext_sweep(ITEM, cfg.a0, cfg.b0)   # poisson_mf_extended_cavi.py:163-215
-            self.history_["iterations"] = it
+            self._tick(it)
             if monitor is None:
                 continue
             val_rmse, _ = monitor()

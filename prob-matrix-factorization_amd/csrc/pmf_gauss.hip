@@ -74,20 +74,28 @@ __device__ __forceinline__ void tri_rc(int p, int &r, int &c) {
 }
 
 // ---------------------------------------------------------------------------
-// accumulate, generic (any K <= 256, fp32 / fp64)
+// accumulate, generic (any K <= 128, fp32 / fp64): VALU outer products
 // ---------------------------------------------------------------------------
+// One wavefront per task.  The packed range is covered in passes of 64 x CH
+// 4-element chunks (lane owns chunks q = lane + 64 s of the pass); per pass the
+// task's ratings are streamed two at a time: their mean rows are staged in LDS
+// (the outer product needs m[r] m[c] for every packed entry), their covariance
+// chunks are loaded as 16/32-byte accesses (2 x CH in flight per lane) and
+// acc += V + m[r] m[c].  The (r, c) of a lane's entries are pass constants.
 template <typename T>
 __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T> p) {
-    constexpr int EPL = 8;  // packed entries per lane per pass
+    constexpr int CH = 4;  // chunks per lane per pass -> 64 * CH * 4 = 1024 packed entries per pass
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
     if (task_id >= p.n_tasks) return;
     const PmfTask t = load_task_uniform(p.tasks, task_id);
-    T *mrow = reinterpret_cast<T *>(smem_raw) + wave * p.kpad;
+    T *m0 = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * 2 * p.kpad;
+    T *m1 = m0 + p.kpad;
     const int32_t *col = p.other + t.start;
     const T *val = p.val + t.start;
     const T b_self = p.bias_self ? p.bias_self[t.row] : (T)0;
+    const int chunks = p.cov_stride / PMF_VEC;
     T *out_s, *out_w;
     if (t.slot >= 0) {
         out_s = p.partial + (int64_t)t.slot * (p.cov_stride + p.kpad);
@@ -96,46 +104,72 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
         out_s = p.dst_s + (int64_t)t.row * p.dst_s_stride;
         out_w = p.dst_w + (int64_t)t.row * p.dst_w_stride;
     }
-    T wacc[4] = {(T)0, (T)0, (T)0, (T)0};
-    for (int p0 = 0; p0 < p.cov_stride; p0 += 64 * EPL) {
-        int rr[EPL], cc[EPL];
-        T acc[EPL];
+    T wacc[2] = {(T)0, (T)0};  // K <= 128: k = lane, lane + 64
+    for (int q0 = 0; q0 < chunks; q0 += 64 * CH) {
+        Vec4<T> acc[CH];
+        int rc[CH][PMF_VEC];  // r | c << 8 of every entry this lane owns in this pass
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int pi = p0 + e * 64 + lane;
-            rr[e] = 0;
-            cc[e] = 0;
-            if (pi < p.kp) tri_rc(pi, rr[e], cc[e]);
-            acc[e] = (T)0;
+        for (int s = 0; s < CH; ++s) {
+            acc[s] = zero4<T>();
+            const int q = q0 + lane + 64 * s;
+#pragma unroll
+            for (int e = 0; e < PMF_VEC; ++e) {
+                int r = 0, c = 0;
+                const int pi = q * PMF_VEC + e;
+                if (q < chunks && pi < p.kp) tri_rc(pi, r, c);
+                rc[s][e] = r | (c << 8);
+            }
         }
-        for (int j = 0; j < t.len; ++j) {
-            const int o = col[j];
-            for (int k = lane; k < p.kpad; k += 64) mrow[k] = p.factor_other[(int64_t)o * p.kpad + k];
-            wave_lds_fence();
-            if (p0 == 0) {
-                const T resid = val[j] - b_self - (p.bias_other ? p.bias_other[o] : (T)0);
+        for (int j = 0; j < t.len; j += 2) {
+            const bool two = j + 1 < t.len;
+            const int o0 = col[j], o1 = two ? col[j + 1] : o0;
+            for (int k = lane; k < p.kpad; k += 64) {
+                m0[k] = p.factor_other[(int64_t)o0 * p.kpad + k];
+                m1[k] = two ? p.factor_other[(int64_t)o1 * p.kpad + k] : (T)0;
+            }
+            const T *v0 = p.cov_other + (int64_t)o0 * p.cov_stride;
+            const T *v1 = p.cov_other + (int64_t)o1 * p.cov_stride;
+            Vec4<T> a[CH], b[CH];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+            for (int s = 0; s < CH; ++s) {
+                const int q = min(q0 + lane + 64 * s, chunks - 1);  // clamped lanes are never stored
+                a[s] = load4(v0 + (int64_t)q * PMF_VEC);
+                b[s] = two ? load4(v1 + (int64_t)q * PMF_VEC) : zero4<T>();
+            }
+            wave_lds_fence();
+            if (q0 == 0) {
+                const T r0 = val[j] - b_self - (p.bias_other ? p.bias_other[o0] : (T)0);
+                const T r1 = two ? val[j + 1] - b_self - (p.bias_other ? p.bias_other[o1] : (T)0) : (T)0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
                     const int k = lane + 64 * e;
-                    if (k < p.K) wacc[e] += mrow[k] * resid;
+                    if (k < p.K) wacc[e] += m0[k] * r0 + m1[k] * r1;
                 }
             }
-            const T *vrow = p.cov_other + (int64_t)o * p.cov_stride;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int pi = p0 + e * 64 + lane;
-                if (pi < p.kp) acc[e] += fma(mrow[rr[e]], mrow[cc[e]], vrow[pi]);
-            }
+            for (int s = 0; s < CH; ++s)
+#pragma unroll
+                for (int e = 0; e < PMF_VEC; ++e) {
+                    const int r = rc[s][e] & 255, c = rc[s][e] >> 8;
+                    // reference order: (V_j + m_j m_j^T) added rating by rating
+                    acc[s].v[e] += fma(m0[r], m0[c], a[s].v[e]);
+                    acc[s].v[e] += fma(m1[r], m1[c], b[s].v[e]);
+                }
             wave_lds_fence();
         }
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int pi = p0 + e * 64 + lane;
-            if (pi < p.cov_stride) out_s[pi] = pi < p.kp ? acc[e] : (T)0;
+        for (int s = 0; s < CH; ++s) {
+            const int q = q0 + lane + 64 * s;
+            if (q < chunks) {
+#pragma unroll
+                for (int e = 0; e < PMF_VEC; ++e)
+                    if (q * PMF_VEC + e >= p.kp) acc[s].v[e] = (T)0;
+                store4(out_s + (int64_t)q * PMF_VEC, acc[s]);
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
         const int k = lane + 64 * e;
         if (k < p.kpad) out_w[k] = k < p.K ? wacc[e] : (T)0;
     }
@@ -152,7 +186,7 @@ struct SolveParams {
     T *cov;
     T *factor;
     T inv_sigma2, inv_eta2;
-    int K, kpad, cov_stride;
+    int K, kpad, kp, cov_stride;
 };
 
 __device__ __forceinline__ float readlane_dyn(float x, int lane) {
@@ -252,107 +286,100 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
                             p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, lane);
 }
 
-// 64 < K <= 128, fp32: the same sweep with two columns per lane (j0 = lane,
-// j1 = lane + 64) and 128 row registers per column set -- 256 VGPRs of matrix,
-// one wavefront per SIMD.  The pivot loop is split at 64 so that the register
-// the pivot column is read from stays a compile-time choice.
-__device__ __forceinline__ void solve_from_image_wide(const float *img, float w0, float w1, int K, int kpad,
-                                                      float inv_sigma2, float inv_eta2, float *vout, float *mout,
-                                                      int lane) {
+// 64 < K <= 128, fp32: the same rotating sweep shared by the TWO wavefronts of a
+// 128-thread block -- wave w owns columns [64w, 64w + 64) of all 128 rows (128 row
+// registers, lane = column).  Each step both waves publish their half of the pivot
+// row in LDS; by symmetry that row is also the pivot column, so the per-row scalars
+// s_i come back as uniform-address LDS reads (hardware broadcast) and the update is
+// one ds_read_b32 + one v_fma per row -- no v_readlane, one barrier per step
+// (the exchange buffer is double-buffered and stored twice so that the rotated row
+// index k + i needs no wrap).
+__global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<float> p) {
     constexpr int KR = 128;
-    float B0[KR], B1[KR];
-    const int j0 = lane, j1 = lane + 64;
-    const int j0c = j0 < K ? j0 : 0, j1c = j1 < K ? j1 : 0;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const int ic = i < K ? i : 0;
-        int lo = ic < j0c ? ic : j0c, hi = ic < j0c ? j0c : ic;
-        float s0 = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
-        lo = ic < j1c ? ic : j1c;
-        hi = ic < j1c ? j1c : ic;
-        float s1 = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
-        if (!(i < K && j0 < K)) s0 = 0.f;
-        if (!(i < K && j1 < K)) s1 = 0.f;
-        if (i == j0) s0 += (i < K) ? inv_eta2 : 1.f;
-        if (i == j1) s1 += (i < K) ? inv_eta2 : 1.f;
-        B0[i] = s0;
-        B1[i] = s1;
-    }
-    float d0 = 1.f, d1 = 1.f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const float a = readlane_dyn(B0[i], i), b = readlane_dyn(B1[i + 64], i);
-        if (lane == i) {
-            d0 = a;
-            d1 = b;
-        }
-    }
-    const float g0 = 1.f / sqrtf(d0), g1 = 1.f / sqrtf(d1);
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const float gi = i < 64 ? readlane_dyn(g0, i) : readlane_dyn(g1, i - 64);
-        B0[i] = B0[i] * g0 * gi;
-        B1[i] = B1[i] * g1 * gi;
-    }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll 1
-        for (int kk = 0; kk < 64; ++kk) {
-            const float v0 = B0[0], v1 = B1[0];
-            const float piv = half == 0 ? readlane_dyn(v0, kk) : readlane_dyn(v1, kk);
-            const float pinv = 1.f / piv;
-            const float u0 = v0 * pinv, u1 = v1 * pinv;
-            const bool at0 = (half == 0) && (lane == kk), at1 = (half == 1) && (lane == kk);
-            const float uc0 = at0 ? (1.f - pinv) : u0, uc1 = at1 ? (1.f - pinv) : u1;
-#pragma unroll
-            for (int i0 = 1; i0 < KR; i0 += 32) {
-                float sc[32];
-#pragma unroll
-                for (int q = 0; q < 32; ++q)
-                    if (i0 + q < KR)
-                        sc[q] = half == 0 ? readlane_dyn(B0[i0 + q], kk) : readlane_dyn(B1[i0 + q], kk);
-#pragma unroll
-                for (int q = 0; q < 32; ++q)
-                    if (i0 + q < KR) {
-                        B0[i0 + q - 1] = fmaf(-sc[q], uc0, B0[i0 + q]);
-                        B1[i0 + q - 1] = fmaf(-sc[q], uc1, B1[i0 + q]);
-                    }
-            }
-            B0[KR - 1] = at0 ? -pinv : u0;
-            B1[KR - 1] = at1 ? -pinv : u1;
-        }
-    }
-    float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const float gi = i < 64 ? readlane_dyn(g0, i) : readlane_dyn(g1, i - 64);
-        const float wi = i < 64 ? readlane_dyn(w0, i) : readlane_dyn(w1, i - 64);
-        const float a = -B0[i] * g0 * gi, b = -B1[i] * g1 * gi;
-        m0 = fmaf(a, wi, m0);
-        m1 = fmaf(b, wi, m1);
-        if (i < K) {
-            if (j0 <= i) vout[i * (i + 1) / 2 + j0] = a;
-            if (j1 <= i) vout[i * (i + 1) / 2 + j1] = b;
-        }
-    }
-    if (j0 < kpad) mout[j0] = (j0 < K) ? m0 * inv_sigma2 : 0.f;
-    if (j1 < kpad) mout[j1] = (j1 < K) ? m1 * inv_sigma2 : 0.f;
-}
-
-__global__ __launch_bounds__(64) void gauss_solve_wide_kernel(SolveParams<float> p) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int lane = threadIdx.x;
+    float *img = reinterpret_cast<float *>(smem_raw);  // packed S, region sized for K = 128 (8256 floats)
+    float *xbuf = img + 8256;                          // [2][256] pivot row, doubled
+    float *gbuf = xbuf + 512;                          // [128] Jacobi scales
+    float *wbuf = gbuf + 128;                          // [128] right-hand side
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t idx = blockIdx.x;
-    const int row = p.rows ? rfl(p.rows[idx]) : (int)idx;
+    const int row = p.rows ? p.rows[idx] : (int)idx;
     const float *S = p.src_s + (int64_t)row * p.src_s_stride;
-    if (!p.rows && S[0] == 0.f) return;
-    float *img = reinterpret_cast<float *>(smem_raw);
-    for (int q = lane * PMF_VEC; q < p.cov_stride; q += 64 * PMF_VEC) store4(img + q, load4(S + q));
-    wave_lds_fence();
-    const float *w = p.src_w + (int64_t)row * p.src_w_stride;
-    const float w0 = lane < p.K ? w[lane] : 0.f, w1 = lane + 64 < p.K ? w[lane + 64] : 0.f;
-    solve_from_image_wide(img, w0, w1, p.K, p.kpad, p.inv_sigma2, p.inv_eta2,
-                          p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, lane);
+    if (!p.rows && S[0] == 0.f) return;  // uniform for the whole block
+    const int K = p.K, j = 64 * wave + lane;
+    // LDS image of the full 128 x 128 lower triangle: the packed S for rows < K, and for the
+    // padding rows >= K zeros with a diagonal chosen so that P_ii = S_ii/sigma2 + 1/eta2 = 1.
+    // With that the register build below needs no K-dependent masks at all.
+    const float pad_diag = (1.f - p.inv_eta2) / p.inv_sigma2;
+    for (int q = threadIdx.x * PMF_VEC; q < 8256; q += 128 * PMF_VEC) {
+        Vec4<float> v = q < p.cov_stride ? load4(S + q) : zero4<float>();
+        if (q + PMF_VEC > p.kp) {
+#pragma unroll
+            for (int e = 0; e < PMF_VEC; ++e)
+                if (q + e >= p.kp) {
+                    int r, c;
+                    tri_rc(q + e, r, c);
+                    v.v[e] = (r == c) ? pad_diag : 0.f;
+                }
+        }
+        store4(img + q, v);
+    }
+    wbuf[j] = j < K ? p.src_w[(int64_t)row * p.src_w_stride + j] : 0.f;
+    __syncthreads();
+    const float g = 1.f / sqrtf(img[j * (j + 3) / 2] * p.inv_sigma2 + p.inv_eta2);
+    gbuf[j] = g;
+    __syncthreads();
+    float B[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        float v = img[hi * (hi + 1) / 2 + lo] * p.inv_sigma2;
+        if (i == j) v += p.inv_eta2;
+        B[i] = v * g * gbuf[i];
+        if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from piling up in VGPRs
+    }
+#pragma unroll 1
+    for (int k = 0; k < KR; ++k) {
+        const float v = B[0];
+        float *xb = xbuf + (k & 1) * 256;
+        xb[j] = v;
+        xb[128 + j] = v;
+        __syncthreads();
+        const float *sk = xb + k;  // sk[i] = element (k + i) mod 128 of the pivot row = s of register i
+        const float pinv = 1.f / sk[0];
+        const float u = v * pinv;
+        const float uc = (j == k) ? (1.f - pinv) : u;
+        // batches of 16 scalars: keeps the live set at ~150 VGPRs (3 waves per SIMD) instead of
+        // letting the scheduler hoist all 127 LDS reads into registers
+#pragma unroll
+        for (int i0 = 1; i0 < KR; i0 += 16) {
+            float sc[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (i0 + q < KR) sc[q] = sk[i0 + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (i0 + q < KR) B[i0 + q - 1] = fmaf(-sc[q], uc, B[i0 + q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        B[KR - 1] = (j == k) ? -pinv : u;
+    }
+    // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
+    // (the bound of the packed output as a VECTOR value: a scalar `i < K` would make the
+    //  compiler keep 128 masks in SGPRs and spill them)
+    int kpv = p.kp;
+    asm volatile("" : "+v"(kpv));
+    float *vout = p.cov + (int64_t)row * p.cov_stride;
+    float mj = 0.f;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const float vij = -B[i] * g * gbuf[i];
+        mj = fmaf(vij, wbuf[i], mj);
+        const int at = i * (i + 1) / 2 + j;
+        if (j <= i && at < kpv) vout[at] = vij;
+        if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (j < p.kpad) p.factor[(int64_t)row * p.kpad + j] = (j < K) ? mj * p.inv_sigma2 : 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -836,7 +863,7 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
         }
         if (!fast)
             hipLaunchKernelGGL((gauss_accum_generic_kernel<T>), grid, dim3(256),
-                               (size_t)4 * ctx->kpad * sizeof(T), ctx->stream, p);
+                               (size_t)4 * 2 * ctx->kpad * sizeof(T), ctx->stream, p);
     }
     if (tl.n_split > 0) {
         PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_COMBINE);
@@ -884,6 +911,7 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     sp.inv_eta2 = (T)(1.0 / eta2);
     sp.K = ctx->K;
     sp.kpad = ctx->kpad;
+    sp.kp = ctx->kp;
     sp.cov_stride = ctx->cov_stride;
     if (sp.n == 0) return PMF_OK;
     PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_SOLVE);
@@ -893,8 +921,8 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (ctx->K <= 64) launch_solve_reg<T, 64>(ctx, sp);
     else if (std::is_same<T, float>::value && !getenv("PMF_GAUSS_LDS_SOLVE")) {
         if constexpr (std::is_same<T, float>::value)
-            hipLaunchKernelGGL(gauss_solve_wide_kernel, dim3((unsigned)sp.n), dim3(64),
-                               (size_t)ctx->cov_stride * sizeof(float), ctx->stream, sp);
+            hipLaunchKernelGGL(gauss_solve_pair_kernel, dim3((unsigned)sp.n), dim3(128),
+                               ((size_t)8256 + 512 + 256) * sizeof(float), ctx->stream, sp);
     } else {
         const int K = ctx->K;
         size_t smem = ((size_t)K * (K + 1) + 3 * K) * sizeof(T);

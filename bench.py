@@ -189,7 +189,8 @@ def main():
 
     # ---- data + state (untimed) ------------------------------------------
     t0 = time.time()
-    u, i, r = synth_ratings(U, I, N, seed=BASE_SEED + rank)
+    # every rank draws its own users / ratings over the same item catalogue
+    u, i, r = synth_ratings(U, I, N, seed=BASE_SEED + rank, item_seed=(BASE_SEED if world > 1 else None))
     t_gen = time.time() - t0
     ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -9,13 +9,18 @@ RATING_MIX = np.array([0.032, 0.006, 0.012, 0.036, 0.142, 0.772])
 BASE_SEED = 20251226
 
 
-def synth_ratings(n_users, n_items, nnz, seed=BASE_SEED, rank=16, chunk=4_000_000):
-    """Returns (u int32, i int32, rating float64 in 0..5)."""
+def synth_ratings(n_users, n_items, nnz, seed=BASE_SEED, rank=16, chunk=4_000_000, item_seed=None):
+    """Returns (u int32, i int32, rating float64 in 0..5).
+
+    `item_seed` fixes the item side (popularity permutation, planted item factors)
+    independently of `seed`: the shards of a multi-GPU run draw different users and
+    ratings (seed + rank) over the SAME item catalogue."""
     rng = np.random.default_rng(seed)
+    rng_items = rng if item_seed is None else np.random.default_rng(item_seed)
     perm_u = rng.permutation(n_users).astype(np.int32)
-    perm_i = rng.permutation(n_items).astype(np.int32)
+    perm_i = rng_items.permutation(n_items).astype(np.int32)
     theta = rng.gamma(0.3, 1.0, size=(n_users, rank)).astype(np.float32)
-    beta = rng.gamma(0.3, 1.0, size=(n_items, rank)).astype(np.float32)
+    beta = rng_items.gamma(0.3, 1.0, size=(n_items, rank)).astype(np.float32)
     # scale so the planted Poisson mean is 4.4 on average
     scale = 4.4 / (float(theta.mean()) * float(beta.mean()) * rank)
     u = np.empty(nnz, dtype=np.int32)

@@ -95,3 +95,46 @@ def test_gaussian_full_size_sampled_rows(ratings):
         res_b = x[sel] - b_item[i[sel]] - mo @ m_theta[rr]
         var = 1.0 / (1.0 + len(sel) / 0.3)
         assert b_new[rr] == pytest.approx(var / 0.3 * res_b.sum(), rel=2e-3, abs=2e-5)
+
+
+def test_gaussian_full_size_item_side_heaviest_rows(ratings):
+    """Item half-sweep at full size from a synthetic user state (V_theta = c I, random
+    means): the 1M-rating item goes through ~2,100 partial chunks, the slot-ordered
+    combine and the standalone solve; light items through the fused kernel."""
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER
+    u, i, r = ratings
+    x = r - r.mean()
+    rng = np.random.default_rng(2)
+    m_theta = 0.3 * rng.standard_normal((U, K))
+    b_user = 0.05 * rng.standard_normal(U)
+    b_item = 0.05 * rng.standard_normal(I)
+    c_scale = 0.25
+    with pmf_hip.Context(U, I, K, dtype="f32") as ctx:
+        ctx.set_ratings(u, i, x)
+        ctx.set_array(USER, ARR_FACTOR, m_theta); ctx.set_array(ITEM, ARR_FACTOR, np.zeros((I, K)))
+        ctx.set_cov_identity(USER, c_scale); ctx.set_cov_identity(ITEM, 1.0)
+        ctx.set_array(USER, ARR_BIAS, b_user); ctx.set_array(ITEM, ARR_BIAS, b_item)
+        ctx.gauss_factor_sweep(ITEM, 0.3, 0.5)
+        m_beta = ctx.get_array(ITEM, ARR_FACTOR)
+        V_beta = ctx.get_array(ITEM, ARR_COV)
+    deg_i = np.bincount(i, minlength=I)
+    heavy = np.argsort(-deg_i)[:3]
+    rows = np.concatenate([heavy, rng.choice(I, 8, replace=False)])
+    assert deg_i[heavy[0]] > 500_000
+    order = np.argsort(i, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(deg_i)])
+    mt32 = m_theta.astype(np.float32).astype(np.float64)
+    for rr in rows:
+        sel = order[ptr[rr]:ptr[rr + 1]]
+        if len(sel) == 0:
+            assert not m_beta[rr].any() and np.array_equal(V_beta[rr], np.eye(K))
+            continue
+        mo = mt32[u[sel]]
+        P = np.eye(K) / 0.5 + (len(sel) * c_scale * np.eye(K) + mo.T @ mo) / 0.3
+        V = np.linalg.inv(P)
+        resid = x[sel] - b_item[rr] - b_user[u[sel]]
+        want = V @ (mo * resid[:, None]).sum(axis=0) / 0.3
+        # fp32 sums over up to 1M ratings: relative to the row's scale
+        assert np.max(np.abs(V_beta[rr] - V)) <= 2e-3 * np.abs(V).max(), (rr, len(sel))
+        assert np.max(np.abs(m_beta[rr] - want)) <= 2e-3 * max(np.abs(want).max(), 1e-3), (rr, len(sel))

@@ -294,47 +294,32 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
 // one ds_read_b32 + one v_fma per row -- no v_readlane, one barrier per step
 // (the exchange buffer is double-buffered and stored twice so that the rotated row
 // index k + i needs no wrap).
-__global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<float> p) {
+//
+// LDS layout shared with the K <= 128 accumulate kernel:
+//   img [8256]  full 128-row packed lower triangle: S for rows < K; for the padding rows
+//               >= K zeros with a diagonal chosen so that P_ii = S_ii/sigma2 + 1/eta2 = 1,
+//               which removes every K-dependent mask from the register build
+//   xbuf [2][256], gbuf [128] (Jacobi scales), wbuf [128] (right-hand side)
+#define PAIR_IMG 8256
+#define PAIR_LDS_FLOATS (PAIR_IMG + 512 + 128 + 128)
+
+__device__ __forceinline__ float pair_pad_diag(float inv_sigma2, float inv_eta2) { return (1.f - inv_eta2) / inv_sigma2; }
+
+// Precondition: img / wbuf are complete and the block has synchronised.
+__device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, float *gbuf, const float *wbuf, int K,
+                                                int kp, int kpad, float inv_sigma2, float inv_eta2, float *vout,
+                                                float *mout, int wave, int lane) {
     constexpr int KR = 128;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    float *img = reinterpret_cast<float *>(smem_raw);  // packed S, region sized for K = 128 (8256 floats)
-    float *xbuf = img + 8256;                          // [2][256] pivot row, doubled
-    float *gbuf = xbuf + 512;                          // [128] Jacobi scales
-    float *wbuf = gbuf + 128;                          // [128] right-hand side
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t idx = blockIdx.x;
-    const int row = p.rows ? p.rows[idx] : (int)idx;
-    const float *S = p.src_s + (int64_t)row * p.src_s_stride;
-    if (!p.rows && S[0] == 0.f) return;  // uniform for the whole block
-    const int K = p.K, j = 64 * wave + lane;
-    // LDS image of the full 128 x 128 lower triangle: the packed S for rows < K, and for the
-    // padding rows >= K zeros with a diagonal chosen so that P_ii = S_ii/sigma2 + 1/eta2 = 1.
-    // With that the register build below needs no K-dependent masks at all.
-    const float pad_diag = (1.f - p.inv_eta2) / p.inv_sigma2;
-    for (int q = threadIdx.x * PMF_VEC; q < 8256; q += 128 * PMF_VEC) {
-        Vec4<float> v = q < p.cov_stride ? load4(S + q) : zero4<float>();
-        if (q + PMF_VEC > p.kp) {
-#pragma unroll
-            for (int e = 0; e < PMF_VEC; ++e)
-                if (q + e >= p.kp) {
-                    int r, c;
-                    tri_rc(q + e, r, c);
-                    v.v[e] = (r == c) ? pad_diag : 0.f;
-                }
-        }
-        store4(img + q, v);
-    }
-    wbuf[j] = j < K ? p.src_w[(int64_t)row * p.src_w_stride + j] : 0.f;
-    __syncthreads();
-    const float g = 1.f / sqrtf(img[j * (j + 3) / 2] * p.inv_sigma2 + p.inv_eta2);
+    const int j = 64 * wave + lane;
+    const float g = 1.f / sqrtf(img[j * (j + 3) / 2] * inv_sigma2 + inv_eta2);
     gbuf[j] = g;
     __syncthreads();
     float B[KR];
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
         const int lo = i < j ? i : j, hi = i < j ? j : i;
-        float v = img[hi * (hi + 1) / 2 + lo] * p.inv_sigma2;
-        if (i == j) v += p.inv_eta2;
+        float v = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
+        if (i == j) v += inv_eta2;
         B[i] = v * g * gbuf[i];
         if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from piling up in VGPRs
     }
@@ -349,8 +334,8 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
         const float pinv = 1.f / sk[0];
         const float u = v * pinv;
         const float uc = (j == k) ? (1.f - pinv) : u;
-        // batches of 16 scalars: keeps the live set at ~150 VGPRs (3 waves per SIMD) instead of
-        // letting the scheduler hoist all 127 LDS reads into registers
+        // batches of 16 scalars: keeps the live set small instead of letting the scheduler
+        // hoist all 127 LDS reads into registers
 #pragma unroll
         for (int i0 = 1; i0 < KR; i0 += 16) {
             float sc[16];
@@ -367,9 +352,8 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
     // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
     // (the bound of the packed output as a VECTOR value: a scalar `i < K` would make the
     //  compiler keep 128 masks in SGPRs and spill them)
-    int kpv = p.kp;
+    int kpv = kp;
     asm volatile("" : "+v"(kpv));
-    float *vout = p.cov + (int64_t)row * p.cov_stride;
     float mj = 0.f;
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
@@ -379,7 +363,197 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
         if (j <= i && at < kpv) vout[at] = vij;
         if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
     }
-    if (j < p.kpad) p.factor[(int64_t)row * p.kpad + j] = (j < K) ? mj * p.inv_sigma2 : 0.f;
+    if (j < kpad) mout[j] = (j < K) ? mj * inv_sigma2 : 0.f;
+}
+
+__global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<float> p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *img = reinterpret_cast<float *>(smem_raw);
+    float *xbuf = img + PAIR_IMG, *gbuf = xbuf + 512, *wbuf = gbuf + 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t idx = blockIdx.x;
+    const int row = p.rows ? p.rows[idx] : (int)idx;
+    const float *S = p.src_s + (int64_t)row * p.src_s_stride;
+    if (!p.rows && S[0] == 0.f) return;  // uniform for the whole block
+    const int K = p.K, j = 64 * wave + lane;
+    const float pad_diag = pair_pad_diag(p.inv_sigma2, p.inv_eta2);
+    for (int q = threadIdx.x * PMF_VEC; q < PAIR_IMG; q += 128 * PMF_VEC) {
+        Vec4<float> v = q < p.cov_stride ? load4(S + q) : zero4<float>();
+        if (q + PMF_VEC > p.kp) {
+#pragma unroll
+            for (int e = 0; e < PMF_VEC; ++e)
+                if (q + e >= p.kp) {
+                    int r, c;
+                    tri_rc(q + e, r, c);
+                    v.v[e] = (r == c) ? pad_diag : 0.f;
+                }
+        }
+        store4(img + q, v);
+    }
+    wbuf[j] = j < K ? p.src_w[(int64_t)row * p.src_w_stride + j] : 0.f;
+    __syncthreads();
+    pair_solve_body(img, xbuf, gbuf, wbuf, K, p.kp, p.kpad, p.inv_sigma2, p.inv_eta2,
+                    p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// accumulate (+ fused solve), fp32, 64 < K <= 128: two wavefronts per task
+// ---------------------------------------------------------------------------
+// Wave w streams half of the packed covariance chunks ([w * H, (w+1) * H), up to 17
+// 16-byte chunks per lane) and owns five of the ten lower 32x32 blocks of sum m m^T
+// (wave 0: (0,0) (1,0) (1,1) (2,0) (2,1); wave 1: (2,2) (3,0) (3,1) (3,2) (3,3)).
+// Both waves fold their blocks into the shared LDS image; a complete row is then
+// solved in place by the same two waves (pair_solve_body).
+template <bool FUSE>
+__global__ __launch_bounds__(128, 1) void gauss_accum_mfma128_kernel(GaussParams<float> p, float inv_sigma2, float inv_eta2,
+                                                                     float *cov_self, float *factor_self) {
+    constexpr int NT = 17;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *img = reinterpret_cast<float *>(smem_raw);
+    float *xbuf = img + PAIR_IMG, *gbuf = xbuf + 512, *wbuf = gbuf + 128;
+    const int wave = rfl(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const PmfTask t = load_task_uniform(p.tasks, blockIdx.x);
+    const int h = lane >> 5, c = lane & 31;
+    const int K = p.K, kpad = p.kpad, stride = p.cov_stride, chunks = p.cov_stride / PMF_VEC;
+    const int half = (chunks + 1) / 2;
+    const int q_begin = wave ? half : 0, q_end = wave ? chunks : half;
+    const int nt = (q_end - q_begin + 63) / 64;  // uniform, <= NT
+    const int32_t *col = p.other + t.start;
+    const float *val = p.val + t.start;
+    const float b_self = p.bias_self ? p.bias_self[t.row] : 0.f;
+
+    f32x16 d[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[b][r] = 0.f;
+    float4 acc[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wA = 0.f, wB = 0.f;  // rhs segments 2*wave and 2*wave + 1
+
+    for (int j = 0; j < t.len; j += 2) {
+        const bool two = j + 1 < t.len;
+        const int o0 = col[j], o1 = two ? col[j + 1] : o0;
+        const int oh = h ? o1 : o0;
+        const bool live = (h == 0) || two;
+        const float *mrow = p.factor_other + (int64_t)oh * kpad;
+        float m[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m[b] = (live && 32 * b + c < K) ? mrow[32 * b + c] : 0.f;
+        const float xh = live ? val[j + h] : 0.f;
+        const float res = live ? xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f) : 0.f;
+        const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * stride);
+        const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * stride);
+        float4 a[NT], b[NT];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s < nt) {  // uniform
+                const int q = min(q_begin + lane + 64 * s, q_end - 1);  // clamped lanes are never stored
+                a[s] = v0[q];
+                if (two) b[s] = v1[q];
+            }
+        }
+        wA = fmaf(wave ? m[2] : m[0], res, wA);
+        wB = fmaf(wave ? m[3] : m[1], res, wB);
+        // operand pairs of this wave's five blocks (wave is uniform: scalar selects)
+        const float A0 = wave ? m[2] : m[0], B0 = wave ? m[2] : m[0];
+        const float A1 = wave ? m[3] : m[1], B1 = m[0];
+        const float A2 = wave ? m[3] : m[1], B2 = m[1];
+        const float A3 = wave ? m[3] : m[2], B3 = wave ? m[2] : m[0];
+        const float A4 = wave ? m[3] : m[2], B4 = wave ? m[3] : m[1];
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, d[0], 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, d[1], 0, 0, 0);
+        d[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2, d[2], 0, 0, 0);
+        d[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3, B3, d[3], 0, 0, 0);
+        d[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(A4, B4, d[4], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            acc[s].x += a[s].x + b[s].x;
+            acc[s].y += a[s].y + b[s].y;
+            acc[s].z += a[s].z + b[s].z;
+            acc[s].w += a[s].w + b[s].w;
+        }
+    }
+
+    // ---- fold: image = zeros (+ padding diagonal), then the ten MFMA blocks ----
+    const float pad_diag = pair_pad_diag(inv_sigma2, inv_eta2);
+    for (int q = threadIdx.x * PMF_VEC; q < PAIR_IMG; q += 128 * PMF_VEC) {
+        Vec4<float> v = zero4<float>();
+        if (FUSE && q + PMF_VEC > p.kp) {
+#pragma unroll
+            for (int e = 0; e < PMF_VEC; ++e)
+                if (q + e >= p.kp) {
+                    int r, cc;
+                    tri_rc(q + e, r, cc);
+                    if (r == cc) v.v[e] = pad_diag;
+                }
+        }
+        store4(img + q, v);
+    }
+    __syncthreads();
+    // block (bi, bj) of d[b]: wave 0: (0,0) (1,0) (1,1) (2,0) (2,1); wave 1: (2,2) (3,0) (3,1) (3,2) (3,3)
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const int bi = wave ? (b == 0 ? 2 : 3) : (b == 0 ? 0 : (b <= 2 ? 1 : 2));
+        const int bj = wave ? (b == 0 ? 2 : b - 1) : (b == 0 ? 0 : (b == 2 ? 1 : (b == 4 ? 1 : 0)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int C = 32 * bj + c;
+            if (R < K && C <= R) img[R * (R + 1) / 2 + C] = d[b][r];
+        }
+    }
+    wA += __shfl_xor(wA, 32, 64);
+    wB += __shfl_xor(wB, 32, 64);
+    if (h == 0) {
+        wbuf[64 * wave + c] = wA;
+        wbuf[64 * wave + 32 + c] = wB;
+    }
+    __syncthreads();
+    if (FUSE && t.slot < 0) {
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int q = q_begin + lane + 64 * s;
+            if (s < nt && q < q_end) {
+                float4 mm = reinterpret_cast<float4 *>(img)[q];
+                mm.x += acc[s].x;
+                mm.y += acc[s].y;
+                mm.z += acc[s].z;
+                mm.w += acc[s].w;
+                reinterpret_cast<float4 *>(img)[q] = mm;
+            }
+        }
+        __syncthreads();
+        pair_solve_body(img, xbuf, gbuf, wbuf, K, p.kp, kpad, inv_sigma2, inv_eta2,
+                        cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
+        return;
+    }
+    float *out_s, *out_w;
+    if (t.slot >= 0) {
+        out_s = p.partial + (int64_t)t.slot * (stride + kpad);
+        out_w = out_s + stride;
+    } else {
+        out_s = p.dst_s + (int64_t)t.row * p.dst_s_stride;
+        out_w = p.dst_w + (int64_t)t.row * p.dst_w_stride;
+    }
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        const int q = q_begin + lane + 64 * s;
+        if (s < nt && q < q_end) {
+            const float4 mm = reinterpret_cast<const float4 *>(img)[q];
+            float4 o = acc[s];
+            o.x += mm.x;
+            o.y += mm.y;
+            o.z += mm.z;
+            o.w += mm.w;
+            reinterpret_cast<float4 *>(out_s)[q] = o;
+        }
+    }
+    const int jj = threadIdx.x;
+    if (jj < kpad) out_w[jj] = jj < K ? wbuf[jj] : 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -853,12 +1027,23 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
         dim3 grid((unsigned)((tl.n_tasks + 3) / 4));
         bool fast = false;
         if constexpr (std::is_same<T, float>::value) {
-            if (ctx->K <= 64 && !getenv("PMF_GAUSS_GENERIC")) {
+            if (!getenv("PMF_GAUSS_GENERIC")) {
                 fast = true;
                 const bool fuse = !stats && !getenv("PMF_GAUSS_UNFUSED");
                 *fused = fuse;
-                launch_accum_mfma(ctx, p, grid, fuse, (float)(1.0 / sigma2), (float)(1.0 / eta2),
-                                  (float *)ctx->arr[side][PMF_ARR_COV], (float *)ctx->arr[side][PMF_ARR_FACTOR]);
+                const float is2 = (float)(1.0 / sigma2), ie2 = (float)(1.0 / eta2);
+                float *cov = (float *)ctx->arr[side][PMF_ARR_COV], *fac = (float *)ctx->arr[side][PMF_ARR_FACTOR];
+                if (ctx->K <= 64) {
+                    launch_accum_mfma(ctx, p, grid, fuse, is2, ie2, cov, fac);
+                } else {  // 64 < K <= 128: one 128-thread block (two wavefronts) per task
+                    const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
+                    dim3 g2((unsigned)tl.n_tasks);
+                    if (fuse)
+                        hipLaunchKernelGGL(gauss_accum_mfma128_kernel<true>, g2, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+                    else
+                        hipLaunchKernelGGL(gauss_accum_mfma128_kernel<false>, g2, dim3(128), smem, ctx->stream, p, 0.f, 0.f,
+                                           (float *)nullptr, (float *)nullptr);
+                }
             }
         }
         if (!fast)
@@ -922,7 +1107,7 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (std::is_same<T, float>::value && !getenv("PMF_GAUSS_LDS_SOLVE")) {
         if constexpr (std::is_same<T, float>::value)
             hipLaunchKernelGGL(gauss_solve_pair_kernel, dim3((unsigned)sp.n), dim3(128),
-                               ((size_t)8256 + 512 + 256) * sizeof(float), ctx->stream, sp);
+                               (size_t)PAIR_LDS_FLOATS * sizeof(float), ctx->stream, sp);
     } else {
         const int K = ctx->K;
         size_t smem = ((size_t)K * (K + 1) + 3 * K) * sizeof(T);

@@ -69,7 +69,7 @@ def test_hpf_logical_shards_equal_single_context(K, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 2e-4)])
-@pytest.mark.parametrize("K", [16, 64])
+@pytest.mark.parametrize("K", [16, 64, 96])
 def test_gaussian_logical_shards_equal_single_context(K, dtype, tol):
     import torch
     import pmf_hip

@@ -124,13 +124,14 @@ def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
         assert np.max(np.abs(got[key] - st[key]) / scale) <= tol, key
 
 
-@pytest.mark.parametrize("K", [5, 16, 30, 32, 33, 40, 64])
+@pytest.mark.parametrize("K", [5, 16, 30, 32, 33, 40, 64, 70, 100, 128])
 def test_mfma_kernel_matches_generic_kernel(K, monkeypatch):
-    """The fp32 K <= 64 fast path (MFMA outer products, fused solve) against the
+    """The fp32 fast paths (K <= 64: one wavefront per task; 64 < K <= 128: two) (MFMA outer products, fused solve) against the
     generic accumulate kernel + standalone solve on the same inputs."""
-    fast, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, N=20000)
+    small = dict(N=20000) if K <= 64 else dict(N=12000, I=60)
+    fast, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, **small)
     monkeypatch.setenv("PMF_GAUSS_GENERIC", "1")
-    slow, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, N=20000)
+    slow, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, **small)
     for key in fast:
         assert max_abs(fast[key], slow[key]) <= 3e-5, key
 

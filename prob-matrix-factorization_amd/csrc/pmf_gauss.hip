@@ -405,7 +405,7 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
 // Both waves fold their blocks into the shared LDS image; a complete row is then
 // solved in place by the same two waves (pair_solve_body).
 template <bool FUSE>
-__global__ __launch_bounds__(128, 1) void gauss_accum_mfma128_kernel(GaussParams<float> p, float inv_sigma2, float inv_eta2,
+__global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams<float> p, float inv_sigma2, float inv_eta2,
                                                                      float *cov_self, float *factor_self) {
     constexpr int NT = 17;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -445,16 +445,14 @@ __global__ __launch_bounds__(128, 1) void gauss_accum_mfma128_kernel(GaussParams
         const float res = live ? xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f) : 0.f;
         const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * stride);
         const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * stride);
-        float4 a[NT], b[NT];
+        // one rating's chunks in flight at a time (68 VGPRs): with the MFMA blocks the kernel then
+        // fits 256 registers, i.e. two blocks' worth of waves per SIMD, so one block can solve
+        // while the other streams
+        float4 a[NT];
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
             a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s < nt) {  // uniform
-                const int q = min(q_begin + lane + 64 * s, q_end - 1);  // clamped lanes are never stored
-                a[s] = v0[q];
-                if (two) b[s] = v1[q];
-            }
+            if (s < nt) a[s] = v0[min(q_begin + lane + 64 * s, q_end - 1)];  // clamped lanes are never stored
         }
         wA = fmaf(wave ? m[2] : m[0], res, wA);
         wB = fmaf(wave ? m[3] : m[1], res, wB);
@@ -471,11 +469,27 @@ __global__ __launch_bounds__(128, 1) void gauss_accum_mfma128_kernel(GaussParams
         d[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(A4, B4, d[4], 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
-            acc[s].x += a[s].x + b[s].x;
-            acc[s].y += a[s].y + b[s].y;
-            acc[s].z += a[s].z + b[s].z;
-            acc[s].w += a[s].w + b[s].w;
+            acc[s].x += a[s].x;
+            acc[s].y += a[s].y;
+            acc[s].z += a[s].z;
+            acc[s].w += a[s].w;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s < nt) a[s] = v1[min(q_begin + lane + 64 * s, q_end - 1)];
+            }
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                acc[s].x += a[s].x;
+                acc[s].y += a[s].y;
+                acc[s].z += a[s].z;
+                acc[s].w += a[s].w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- fold: image = zeros (+ padding diagonal), then the ten MFMA blocks ----

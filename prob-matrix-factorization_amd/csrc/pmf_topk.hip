@@ -87,13 +87,99 @@ __device__ __forceinline__ bool ranks_before(S v1, int i1, S v2, int i2) {
     return v1 > v2 || (v1 == v2 && i1 < i2);
 }
 
+// wave arg-best under (value desc, index asc); every lane returns the winner
+template <typename S>
+__device__ __forceinline__ void wave_best(S &bv, int &bidx, bool &found) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const S ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        const int of = __shfl_xor((int)found, off, 64);
+        if (of && (!found || ranks_before(ov, oi, bv, bidx))) {
+            bv = ov;
+            bidx = oi;
+            found = true;
+        }
+    }
+}
+
+// One wavefront per user, k <= 64.  Two passes over the user's score row instead of k:
+//  (1) per-lane maxima; the k-th largest of the 64 lane maxima is a lower bound tau of the
+//      k-th best score (the k best lane maxima are k distinct entries >= tau);
+//  (2) every entry >= tau is compacted (ballot + prefix) into an LDS candidate list, from
+//      which the k winners are drawn with the deterministic (value desc, index asc) rule.
+// A list that would overflow (massive ties) falls back to the k-pass scan of the row.
+#define TOPK_CAP 1024
 template <typename S>
 __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int nq, int64_t n_items, int k,
                                                           int32_t *out_items, double *out_scores) {
+    __shared__ S c_val[4][TOPK_CAP];
+    __shared__ int c_idx[4][TOPK_CAP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
     const S *row = scores + (int64_t)q * n_items;
+    S *cv = c_val[wave];
+    int *ci = c_idx[wave];
+    int count = -1;  // -1: candidate list unusable -> scan the row itself
+    if (k <= 64) {
+        // pass 1: lane maxima
+        bool have = false;
+        S lm = (S)0;
+        for (int64_t i = lane; i < n_items; i += 64) {
+            const S v = row[i];
+            if (v == v && (!have || v > lm)) {
+                lm = v;
+                have = true;
+            }
+        }
+        // k-th largest lane maximum (values only; ties are harmless for a lower bound)
+        S tau = (S)0;
+        bool tau_ok = false;
+        {
+            bool alive = have;
+            for (int t = 0; t < k; ++t) {
+                S bv = lm;
+                int bidx = lane;
+                bool found = alive;
+                wave_best(bv, bidx, found);
+                tau_ok = found;
+                if (!found) break;
+                tau = bv;
+                if (lane == bidx) alive = false;
+            }
+        }
+        if (tau_ok) {
+            // pass 2: compact entries >= tau
+            count = 0;
+            const int64_t rounds = (n_items + 63) / 64;
+            for (int64_t r = 0; r < rounds && count >= 0; ++r) {
+                const int64_t i = r * 64 + lane;
+                S v = (S)0;
+                bool pred = false;
+                if (i < n_items) {
+                    v = row[i];
+                    pred = (v == v) && v >= tau;
+                }
+                const unsigned long long mask = __ballot(pred);
+                const int n = __popcll(mask);
+                if (n) {
+                    if (count + n > TOPK_CAP) {
+                        count = -1;
+                    } else {
+                        if (pred) {
+                            const int at = count + __popcll(mask & ((1ull << lane) - 1ull));
+                            cv[at] = v;
+                            ci[at] = (int)i;
+                        }
+                        count += n;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     bool have_prev = false;
     S pv = (S)0;
     int pi = -1;
@@ -101,28 +187,30 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int n
         bool found = false;
         S bv = (S)0;
         int bidx = 0x7fffffff;
-        for (int64_t i = lane; i < n_items; i += 64) {
-            const S v = row[i];
-            if (!(v == v)) continue;  // NaN never ranks
-            if (have_prev && !ranks_before(pv, pi, v, (int)i)) continue;
-            if (!found || ranks_before(v, (int)i, bv, bidx)) {
-                bv = v;
-                bidx = (int)i;
-                found = true;
+        if (count >= 0) {
+            for (int e = lane; e < count; e += 64) {
+                const S v = cv[e];
+                const int i = ci[e];
+                if (have_prev && !ranks_before(pv, pi, v, i)) continue;
+                if (!found || ranks_before(v, i, bv, bidx)) {
+                    bv = v;
+                    bidx = i;
+                    found = true;
+                }
+            }
+        } else {
+            for (int64_t i = lane; i < n_items; i += 64) {
+                const S v = row[i];
+                if (!(v == v)) continue;  // NaN never ranks
+                if (have_prev && !ranks_before(pv, pi, v, (int)i)) continue;
+                if (!found || ranks_before(v, (int)i, bv, bidx)) {
+                    bv = v;
+                    bidx = (int)i;
+                    found = true;
+                }
             }
         }
-        // wave arg-max
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const S ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bidx, off, 64);
-            const int of = __shfl_xor((int)found, off, 64);
-            if (of && (!found || ranks_before(ov, oi, bv, bidx))) {
-                bv = ov;
-                bidx = oi;
-                found = true;
-            }
-        }
+        wave_best(bv, bidx, found);
         if (lane == 0) {
             out_items[(int64_t)q * k + t] = found ? bidx : -1;
             out_scores[(int64_t)q * k + t] = found ? (double)bv : 0.0;

@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--small", action="store_true", help="1/10 size functional run (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only", action="store_true", help="skip the secondary HPF-CAVI measurement of the default run")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a single-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0")
@@ -186,79 +187,114 @@ def main():
         w["K"] = args.factors
         w["label"] += f" [K overridden to {args.factors}]"
     U, I, N, K, hp = w["U"], w["I"], w["N"], w["K"], w["hp"]
+    elem = 4 if args.dtype == "f32" else 8
 
-    # ---- data + state (untimed) ------------------------------------------
+    # ---- data (untimed) ----------------------------------------------------
     t0 = time.time()
     # every rank draws its own users / ratings over the same item catalogue
     u, i, r = synth_ratings(U, I, N, seed=BASE_SEED + rank, item_seed=(BASE_SEED if world > 1 else None))
     t_gen = time.time() - t0
-    ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    rng = np.random.default_rng(42)
-    t0 = time.time()
-    gauss = args.workload.startswith("gaussian_mf")
-    if gauss:
-        gm = float(r.mean())
-        ctx.set_ratings(u, i, r - gm)  # centred as compare_models.py:54-65
-    else:
-        ctx.set_ratings(u, i, r + 1.0)  # +1 shift as compare_models.py:180-185
-    t_csr = time.time() - t0
-    del u, i, r
-    stats_item = stats_bias = None
-    if gauss:
-        # gaussian_mf_cavi_bias.py:52-67 initial state
-        ctx.set_array(USER, ARR_FACTOR, 0.1 * rng.standard_normal((U, K)))
-        ctx.set_array(ITEM, ARR_FACTOR, 0.1 * np.random.default_rng(43).standard_normal((I, K)))
-        ctx.set_cov_identity(USER, 1.0)
-        ctx.set_cov_identity(ITEM, 1.0)
-        ctx.set_array(USER, ARR_BIAS, np.zeros(U))
-        ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
-        if comm is not None:
-            stats_item, stats_bias = pdist.gauss_stats(ctx, device)
-
-        def step():
-            pdist.gaussian_iteration(ctx, comm, stats_item, stats_bias, hp["sigma2"], hp["eta_theta2"],
-                                     hp["eta_beta2"], hp["eta_bias2"])
-        dominant = "gauss_accum"
-    else:
-        # hpf_cavi.py:66-89 initial state
-        ctx.set_array(USER, ARR_FACTOR, (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K))))
-        r2 = np.random.default_rng(43)
-        ctx.set_array(ITEM, ARR_FACTOR, (hp["c"] + r2.gamma(1.0, 0.1, (I, K))) / (hp["d_prime"] + r2.gamma(1.0, 0.1, (I, K))))
-        ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, (hp["a_prime"] + K * hp["a"]) / hp["b_prime"]))
-        ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, (hp["c_prime"] + K * hp["c"]) / hp["d_prime"]))
-        if comm is not None:
-            stats_item = pdist.gamma_stats(ctx, device)
-        up = (hp["a"], 0.0, True, hp["a_prime"] + K * hp["a"], hp["b_prime"])
-        ip = (hp["c"], 0.0, True, hp["c_prime"] + K * hp["c"], hp["d_prime"])
-
-        def step():
-            pdist.gamma_iteration(ctx, comm, stats_item, up, ip)
-        dominant = "gamma_sweep"
 
     def fence():
         if comm is not None:
             comm.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.prof_get()
-    ctx.prof_enable(False)
+    def run(workload, hp, steps, warmup):
+        """Build the device state of `workload` on the shared ratings, run warmup + timed steps
+        (barrier + synchronize on both sides, max over ranks) and return the measurements."""
+        gauss = workload.startswith("gaussian_mf")
+        ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        rng = np.random.default_rng(42)
+        t0 = time.time()
+        if gauss:
+            ctx.set_ratings(u, i, r - float(r.mean()))  # centred as compare_models.py:54-65
+        else:
+            ctx.set_ratings(u, i, r + 1.0)              # +1 shift as compare_models.py:180-185
+        t_csr = time.time() - t0
+        stats_item = stats_bias = None
+        if gauss:
+            # gaussian_mf_cavi_bias.py:52-67 initial state
+            ctx.set_array(USER, ARR_FACTOR, 0.1 * rng.standard_normal((U, K)))
+            ctx.set_array(ITEM, ARR_FACTOR, 0.1 * np.random.default_rng(43).standard_normal((I, K)))
+            ctx.set_cov_identity(USER, 1.0)
+            ctx.set_cov_identity(ITEM, 1.0)
+            ctx.set_array(USER, ARR_BIAS, np.zeros(U))
+            ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
+            if comm is not None:
+                stats_item, stats_bias = pdist.gauss_stats(ctx, device)
 
-    if comm is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        import torch.distributed as tdist
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            def step():
+                pdist.gaussian_iteration(ctx, comm, stats_item, stats_bias, hp["sigma2"], hp["eta_theta2"],
+                                         hp["eta_beta2"], hp["eta_bias2"])
+            dominant = "gauss_accum"
+        else:
+            # hpf_cavi.py:66-89 initial state
+            ctx.set_array(USER, ARR_FACTOR, (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K))))
+            r2 = np.random.default_rng(43)
+            ctx.set_array(ITEM, ARR_FACTOR, (hp["c"] + r2.gamma(1.0, 0.1, (I, K))) / (hp["d_prime"] + r2.gamma(1.0, 0.1, (I, K))))
+            ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, (hp["a_prime"] + K * hp["a"]) / hp["b_prime"]))
+            ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, (hp["c_prime"] + K * hp["c"]) / hp["d_prime"]))
+            if comm is not None:
+                stats_item = pdist.gamma_stats(ctx, device)
+            up = (hp["a"], 0.0, True, hp["a_prime"] + K * hp["a"], hp["b_prime"])
+            ip = (hp["c"], 0.0, True, hp["c_prime"] + K * hp["c"], hp["d_prime"])
+
+            def step():
+                pdist.gamma_iteration(ctx, comm, stats_item, up, ip)
+            dominant = "gamma_sweep"
+
+        for _ in range(warmup):
+            step()
+        fence()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = ctx.prof_get()
+        ctx.prof_enable(False)
+        if comm is not None:
+            import torch.distributed as tdist
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        total_bytes, dom_bytes = algorithmic_bytes(workload, U, I, N, K, elem)
+        dom_ms, dom_n = prof[dominant]
+        achieved = (dom_bytes / 2) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0  # two launches per epoch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and not args.small and args.dtype == "f32" and not args.factors:
+            try:
+                traffic = json.load(open(tpath)).get(f"{workload}:{dominant}")
+            except Exception:
+                traffic = None
+        res = {
+            "value": world * N * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "epoch_algorithmic_GB": total_bytes / 1e9,
+            "epoch_fraction_of_hbm_roofline": (total_bytes / (elapsed / steps)) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n},
+            "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
+            "csr_build_and_upload_s": t_csr, "device_GB": ctx.device_bytes() / 1e9,
+        }
+        ctx.close()
+        del stats_item, stats_bias
+        torch.cuda.empty_cache()
+        return res
+
+    gauss = args.workload.startswith("gaussian_mf")
+    main_res = run(args.workload, hp, args.steps, args.warmup)
+    also = None
+    if args.workload == "gaussian_mf" and not args.only:
+        # the north star names both models: HPF-CAVI on the same ratings (+1), same protocol
+        also = run("hpf_cavi", WORKLOADS["hpf_cavi"]["hp"], max(args.steps, 10), max(args.warmup, 2))
+    del u, i, r
+
     if rank != 0:
         if comm is not None:
             comm.barrier()
@@ -266,38 +302,27 @@ def main():
             tdist.destroy_process_group()
         return
 
-    elem = 4 if args.dtype == "f32" else 8
-    total_bytes, dom_bytes = algorithmic_bytes(args.workload, U, I, N, K, elem)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * N * args.steps / elapsed
-    dom_ms, dom_n = prof[dominant]
-    per_iter_launches = 2
-    achieved = (dom_bytes / per_iter_launches) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and not args.small and args.dtype == "f32":
-        try:
-            traffic = json.load(open(tpath)).get(f"{args.workload}:{dominant}")
-        except Exception:
-            traffic = None
     out = {
         "metric": f"ratings/sec (epoch) Gaussian-MF K={K}" if gauss else f"ratings/sec (epoch) HPF-CAVI K={K}",
-        "value": value, "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": main_res["value"], "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": w["label"] + (" [--small]" if args.small else ""), "n_users_per_gpu": U,
                    "n_items": I, "ratings_per_gpu": N, "n_factors": K,
                    "parallelism": f"user-range rating shards x{world}, item statistics all-reduce (RCCL)"
                                   if world > 1 else "single GPU",
-                   "epoch_algorithmic_GB": total_bytes / 1e9,
-                   "epoch_fraction_of_hbm_roofline": (total_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS},
-        "roofline": {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n},
-        "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
-        "setup_s": {"generate": t_gen, "csr_build_and_upload": t_csr},
-        "device_GB": ctx.device_bytes() / 1e9,
+                   "epoch_algorithmic_GB": main_res["epoch_algorithmic_GB"],
+                   "epoch_fraction_of_hbm_roofline": main_res["epoch_fraction_of_hbm_roofline"]},
+        "roofline": main_res["roofline"],
+        "kernels_ms_per_step": main_res["kernels_ms_per_step"],
+        "setup_s": {"generate": t_gen, "csr_build_and_upload": main_res["csr_build_and_upload_s"]},
+        "device_GB": main_res["device_GB"],
     }
+    if also is not None:
+        out["also"] = {"hpf_cavi": {"metric": f"ratings/sec (epoch) HPF-CAVI K={K}", "unit": "ratings/s",
+                                    "value": also["value"], "ms_per_step": also["ms_per_step"], "steps": also["steps"],
+                                    "epoch_fraction_of_hbm_roofline": also["epoch_fraction_of_hbm_roofline"],
+                                    "roofline": also["roofline"]}}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank)
     print(json.dumps(out), flush=True)

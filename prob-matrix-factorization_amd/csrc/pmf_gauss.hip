@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel
                                                                                 float *factor_self) {
     constexpr int NB = KB == 64 ? 3 : 1;
     // (measured at K = 64 / NT = 9: two pairs in flight 1-2 % slower; one rating at a time at 3 waves
-    //  per SIMD 2.5 % slower than one pair at 2 waves per SIMD)
+    //  per SIMD 2.5 % slower than one pair at 2 waves per SIMD; non-temporal loads of the item side's
+    //  streamed-once covariance rows: no difference)
     constexpr int PU = NT >= 5 ? 1 : (NT >= 3 ? 2 : (NT == 2 ? 4 : 8));
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

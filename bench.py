@@ -205,7 +205,8 @@ def main():
         (barrier + synchronize on both sides, max over ranks) and return the measurements."""
         gauss = workload.startswith("gaussian_mf")
         ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # kernels, RCCL collectives and torch allocations share one non-default stream
+        scope = pdist.StreamScope(ctx, device).enter()
         rng = np.random.default_rng(42)
         t0 = time.time()
         if gauss:
@@ -262,6 +263,16 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
             elapsed = float(t.item())
+        consistent = None
+        if comm is not None:
+            # outside the timed region: the replicated item state must be bit-identical on all ranks
+            import hashlib
+            import torch.distributed as tdist
+            digest = hashlib.sha256(ctx.get_array(ITEM, ARR_FACTOR).tobytes()).digest()[:8]
+            mine = torch.tensor(list(digest), dtype=torch.int64, device=device)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            tdist.all_gather(every, mine)
+            consistent = all(bool((e == mine).all().item()) for e in every)
         total_bytes, dom_bytes = algorithmic_bytes(workload, U, I, N, K, elem)
         dom_ms, dom_n = prof[dominant]
         achieved = (dom_bytes / 2) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0  # two launches per epoch
@@ -281,7 +292,9 @@ def main():
                          "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n},
             "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
             "csr_build_and_upload_s": t_csr, "device_GB": ctx.device_bytes() / 1e9,
+            "item_replicas_identical": consistent,
         }
+        scope.exit()
         ctx.close()
         del stats_item, stats_bias
         torch.cuda.empty_cache()
@@ -318,6 +331,8 @@ def main():
         "setup_s": {"generate": t_gen, "csr_build_and_upload": main_res["csr_build_and_upload_s"]},
         "device_GB": main_res["device_GB"],
     }
+    if world > 1:
+        out["config"]["item_replicas_identical"] = main_res["item_replicas_identical"]
     if also is not None:
         out["also"] = {"hpf_cavi": {"metric": f"ratings/sec (epoch) HPF-CAVI K={K}", "unit": "ratings/s",
                                     "value": also["value"], "ms_per_step": also["ms_per_step"], "steps": also["steps"],

@@ -101,7 +101,9 @@ int pmf_ctx_create(int device, int64_t n_users, int64_t n_items, int n_factors, 
                    pmf_ctx **out);
 int pmf_ctx_destroy(pmf_ctx *ctx);
 /* run on an existing HIP stream (e.g. torch's current stream) instead of the
- * context's own; `hip_stream` is a hipStream_t.  NULL restores the own stream. */
+ * context's own; `hip_stream` is a hipStream_t.  NULL restores the own stream -- so the
+ * null handle of the legacy default stream cannot be selected: order with torch / RCCL
+ * through a non-default stream (pmf_hip/dist.py:StreamScope). */
 int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream);
 int pmf_ctx_sync(pmf_ctx *ctx);
 /* bytes of device memory currently held by the context */

@@ -103,6 +103,42 @@ def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2,
         engine.gauss_bias_finalize(ITEM, stats_bias.ptr, sigma2, eta_bias2)
 
 
+class StreamScope:
+    """Puts one engine context and torch (its allocator, its collectives) on the SAME
+    non-default HIP stream, so that kernels, all-reduces and copies are ordered without
+    host synchronisation.  (torch's default stream has the null handle, which
+    `pmf_ctx_set_stream` would read as "use the context's own stream".)
+
+        scope = StreamScope(ctx, device); scope.enter()   ...   scope.exit()
+    """
+
+    def __init__(self, ctx, device):
+        import torch
+        self._torch = torch
+        self.stream = torch.cuda.Stream(device=device)
+        self._ctx = ctx
+        self._cm = None
+
+    def enter(self):
+        assert self.stream.cuda_stream != 0
+        self._ctx.set_stream(self.stream.cuda_stream)
+        self._cm = self._torch.cuda.stream(self.stream)
+        self._cm.__enter__()
+        return self
+
+    def exit(self):
+        if self._cm is not None:
+            self.stream.synchronize()
+            self._cm.__exit__(None, None, None)
+            self._cm = None
+            self._ctx.set_stream(None)
+
+    __enter__ = enter
+
+    def __exit__(self, *exc):
+        self.exit()
+
+
 class DeviceStats:
     """A device buffer owned by torch (so RCCL can all-reduce it) whose raw
     pointer is handed to the C-ABI accumulate / finalize calls."""

@@ -160,12 +160,17 @@ class Context:
                   "pmf_predict")
         return out
 
-    def eval_set(self, user_ids, item_ids, y_true):
+    def eval_set(self, user_ids, item_ids, y_true, labels=None):
         """Store a validation set on the device.  Returns False (and stores
         nothing) when y_true has more than MAX_LABELS distinct values -- the
-        caller then evaluates through `predict`."""
+        caller then evaluates through `predict`.  `labels` (sorted distinct
+        values) fixes the label set, e.g. to the global one of a sharded run."""
         y = as_f64(y_true)
-        labels, inverse = np.unique(y, return_inverse=True)
+        if labels is None:
+            labels, inverse = np.unique(y, return_inverse=True)
+        else:
+            labels = np.asarray(labels, dtype=np.float64)
+            inverse = np.searchsorted(labels, y)
         if len(labels) > MAX_LABELS or len(y) == 0:
             return False
         u, i = self._clip_ids(user_ids), self._clip_ids(item_ids)
@@ -176,17 +181,28 @@ class Context:
         self._eval_n, self._eval_labels = len(y), len(labels)
         return True
 
-    def eval_run(self, use_bias=False, offset=0.0):
-        """(rmse, macro_mae) over the stored validation set (metrics.py:6-10, :37-51)."""
+    def eval_sums(self, use_bias=False, offset=0.0):
+        """Raw reductions over the stored validation set: [n, sum sq err, per-label
+        sum |err| (MAX_LABELS), per-label count (MAX_LABELS)] as one float64 vector
+        (additive across the shards of a multi-GPU run)."""
         sse = C.c_double(0.0)
         abs_l = np.zeros(MAX_LABELS, dtype=np.float64)
         cnt_l = np.zeros(MAX_LABELS, dtype=np.int64)
         check(self._lib.pmf_eval_run(self._h, int(use_bias), float(offset), C.byref(sse),
                                      ptr(abs_l, C.c_double), ptr(cnt_l, C.c_int64)), "pmf_eval_run")
-        L = self._eval_labels
-        rmse = float(np.sqrt(sse.value / self._eval_n))
-        macro = float(np.mean(abs_l[:L] / cnt_l[:L]))
-        return rmse, macro
+        return np.concatenate([[float(self._eval_n), sse.value], abs_l, cnt_l.astype(np.float64)])
+
+    @staticmethod
+    def metrics_from_sums(sums):
+        """(rmse, macro_mae) from an `eval_sums` vector (metrics.py:6-10, :37-51)."""
+        n, sse = sums[0], sums[1]
+        abs_l, cnt_l = sums[2:2 + MAX_LABELS], sums[2 + MAX_LABELS:2 + 2 * MAX_LABELS]
+        seen = cnt_l > 0
+        return float(np.sqrt(sse / n)), float(np.mean(abs_l[seen] / cnt_l[seen]))
+
+    def eval_run(self, use_bias=False, offset=0.0):
+        """(rmse, macro_mae) over the stored validation set."""
+        return self.metrics_from_sums(self.eval_sums(use_bias, offset))
 
     def topk_items(self, user_ids, k, use_bias=False):
         u = as_i32(user_ids, "user_ids")

@@ -39,13 +39,21 @@ class DeviceModel:
 
     _uses_bias = False
 
-    def __init__(self, config, dtype=None, device=None):
+    def __init__(self, config, dtype=None, device=None, comm=None):
+        """`comm`: a `pmf_hip.dist.Comm` (torch.distributed group, one rank per GPU) makes
+        `fit` a user-sharded multi-GPU run: every rank passes the SAME frames, keeps the
+        ratings of its user range, item statistics are all-reduced once per item
+        half-sweep, and every rank ends with the full factor matrices."""
         self.config = config
+        self._comm = comm if (comm is not None and comm.world > 1) else None
+        self._bounds = None
         self.n_users = None
         self.n_items = None
         self._dtype = engine_dtype(dtype)
         self._device = engine_device(device)
         self._ctx = None
+        self._shard_ctx = None
+        self._scope = None
         # structured per-iteration record next to the reference's stdout lines
         self.history_ = {"val_rmse": [], "val_macro_mae": [], "iterations": 0, "stopped_early": False,
                          "seconds": []}
@@ -61,8 +69,22 @@ class DeviceModel:
     def _open_context(self, u, i, x):
         if self._ctx is not None:
             self._ctx.close()
-        self._ctx = pmf_hip.Context(self.n_users, self.n_items, self.config.n_factors,
+        n_local = self.n_users
+        if self._comm is not None:
+            from pmf_hip import dist as pdist
+            self._bounds = pdist.shard_bounds(u, self.n_users, self._comm.world)
+            u, i, x = pdist.take_shard(u, i, x, self._bounds, self._comm.rank)
+            n_local = int(self._bounds[self._comm.rank + 1] - self._bounds[self._comm.rank])
+            if n_local <= 0:
+                raise ValueError("a rank received an empty user range: fewer users than ranks")
+        self._ctx = pmf_hip.Context(n_local, self.n_items, self.config.n_factors,
                                     dtype=self._dtype, device=self._device)
+        if self._comm is not None:
+            import torch
+            from pmf_hip import dist as pdist
+            torch.cuda.set_device(self._device)
+            self._exit_stream()
+            self._scope = pdist.StreamScope(self._ctx, self._device_obj()).enter()
         self._ctx.set_ratings(u, i, x)
         import time
         self._t_last = time.perf_counter()
@@ -70,6 +92,52 @@ class DeviceModel:
             self.history_[key] = []
         self.history_["iterations"], self.history_["stopped_early"] = 0, False
         return self._ctx
+
+    # ---- multi-GPU helpers --------------------------------------------------
+    def _mine(self, full_user_array):
+        """This rank's rows of a full user-side array (the whole array when not sharded)."""
+        if self._comm is None:
+            return full_user_array
+        lo, hi = int(self._bounds[self._comm.rank]), int(self._bounds[self._comm.rank + 1])
+        return full_user_array[lo:hi]
+
+    def _gather_users(self, local):
+        """All ranks' user-side rows, concatenated in user order, on every rank."""
+        if self._comm is None:
+            return local
+        import torch
+        sizes = np.diff(self._bounds).astype(int)
+        width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
+        pad = np.zeros((int(sizes.max()), width))
+        pad[:len(local)] = local.reshape(len(local), width)
+        dev = torch.device("cuda", self._device)
+        mine = torch.from_numpy(pad).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self._comm.world)]
+        self._comm._dist.all_gather(parts, mine, group=self._comm.group)
+        rows = [p.cpu().numpy()[:n] for p, n in zip(parts, sizes)]
+        return np.concatenate(rows, axis=0).reshape((-1,) + local.shape[1:])
+
+    def _exit_stream(self):
+        scope = getattr(self, "_scope", None)
+        if scope is not None:
+            scope.exit()
+            self._scope = None
+
+    def _finish_sharded(self, arrays):
+        """After a sharded fit every rank holds the full factors on the host; give it a
+        full-size context too, so predict / evaluate / top-k work as after a single-GPU fit.
+        `arrays`: [(side, array_id, host_array)].  The training shard stays in `_shard_ctx`."""
+        self._exit_stream()
+        self._shard_ctx = self._ctx
+        full = pmf_hip.Context(self.n_users, self.n_items, self.config.n_factors, dtype=self._dtype,
+                               device=self._device)
+        for side, array_id, host in arrays:
+            full.set_array(side, array_id, host)
+        self._ctx = full
+
+    def _device_obj(self):
+        import torch
+        return torch.device("cuda", self._device)
 
     def _need_ctx(self):
         if self._ctx is None:
@@ -93,6 +161,8 @@ class DeviceModel:
                 return empty
         y = vy + offset if drop_unseen else vy
         ctx = self._ctx
+        if self._comm is not None:
+            return self._sharded_monitor(vu, vi, y, offset)
         if ctx.eval_set(vu, vi, y):
             return lambda: ctx.eval_run(self._uses_bias, offset)
         # too many distinct labels for the fused reduction: device predict + host metrics
@@ -114,6 +184,30 @@ class DeviceModel:
         self._t_last = now
         self.history_["iterations"] = it
 
+    def _sharded_monitor(self, vu, vi, y, offset):
+        """Every rank scores the validation pairs of its own users (pairs with an unseen
+        user go to the last rank, where the id stays out of range and predicts 0); the
+        additive sums are all-reduced."""
+        import torch
+        from pmf_hip import MAX_LABELS
+        comm, ctx = self._comm, self._ctx
+        labels = np.unique(y)
+        if len(labels) > MAX_LABELS:
+            raise NotImplementedError("sharded validation supports at most %d distinct ratings" % MAX_LABELS)
+        lo, hi = int(self._bounds[comm.rank]), int(self._bounds[comm.rank + 1])
+        last = comm.rank == comm.world - 1
+        mine = (vu >= lo) & ((vu < hi) | last)
+        lu = np.where(vu[mine] < self.n_users, vu[mine] - lo, np.iinfo(np.int32).max)
+        have = ctx.eval_set(lu, vi[mine], y[mine], labels=labels) if mine.any() else False
+        dev = self._device_obj()
+
+        def run():
+            sums = ctx.eval_sums(self._uses_bias, offset) if have else np.zeros(2 + 2 * MAX_LABELS)
+            t = torch.from_numpy(sums).to(dev)
+            comm.all_reduce(t)
+            return ctx.metrics_from_sums(t.cpu().numpy())
+        return run
+
     def _record(self, rmse_v, mae_v):
         self.history_["val_rmse"].append(rmse_v)
         self.history_["val_macro_mae"].append(mae_v)
@@ -125,10 +219,13 @@ class DeviceModel:
         return self._need_ctx().topk_items(np.asarray(user_ids, dtype=int), int(k), use_bias=self._uses_bias)
 
     def close(self):
-        """Release the device context (predict is unavailable afterwards)."""
-        if self._ctx is not None:
-            self._ctx.close()
-            self._ctx = None
+        """Release the device context(s) (predict is unavailable afterwards)."""
+        self._exit_stream()
+        for name in ("_ctx", "_shard_ctx"):
+            ctx = getattr(self, name, None)
+            if ctx is not None:
+                ctx.close()
+                setattr(self, name, None)
 
 
 __all__ = ["DeviceModel", "frame_arrays", "USER", "ITEM"]

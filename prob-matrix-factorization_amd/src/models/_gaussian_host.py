@@ -8,12 +8,12 @@ import numpy as np
 
 from src.evaluation.metrics import macro_mae, rmse
 from src.models._device_model import ITEM, USER, DeviceModel, frame_arrays
-from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR
+from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, dist as pdist
 
 
 class GaussianHost(DeviceModel):
-    def __init__(self, config, dtype=None, device=None):
-        super().__init__(config, dtype, device)
+    def __init__(self, config, dtype=None, device=None, comm=None):
+        super().__init__(config, dtype, device, comm)
         self.m_theta = self.m_beta = None
         self._V_theta = self._V_beta = None
         self.global_mean = 0.0
@@ -23,10 +23,13 @@ class GaussianHost(DeviceModel):
     # The covariance stacks are rows x K x K float64 on the host (32 GB at
     # 1M x 64 x 64): they stay packed on the device and are materialised only
     # when the attribute is read.
+    def _train_ctx(self):
+        return getattr(self, "_shard_ctx", None) or self._ctx
+
     @property
     def V_theta(self):
         if self._V_theta is None and self._ctx is not None:
-            self._V_theta = self._ctx.get_array(USER, ARR_COV)
+            self._V_theta = self._gather_users(self._train_ctx().get_array(USER, ARR_COV))
         return self._V_theta
 
     @V_theta.setter
@@ -36,7 +39,7 @@ class GaussianHost(DeviceModel):
     @property
     def V_beta(self):
         if self._V_beta is None and self._ctx is not None:
-            self._V_beta = self._ctx.get_array(ITEM, ARR_COV)
+            self._V_beta = self._train_ctx().get_array(ITEM, ARR_COV)
         return self._V_beta
 
     @V_beta.setter
@@ -55,11 +58,15 @@ class GaussianHost(DeviceModel):
         self._V_theta = self._V_beta = None
 
     def _pull_state(self):
-        ctx = self._ctx
-        self.m_theta, self.m_beta = ctx.get_array(USER, ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
+        ctx, g = self._ctx, self._gather_users
+        self.m_theta, self.m_beta = g(ctx.get_array(USER, ARR_FACTOR)), ctx.get_array(ITEM, ARR_FACTOR)
+        arrays = [(USER, ARR_FACTOR, self.m_theta), (ITEM, ARR_FACTOR, self.m_beta)]
         if self._uses_bias:
-            self.m_user_bias, self.m_item_bias = ctx.get_array(USER, ARR_BIAS), ctx.get_array(ITEM, ARR_BIAS)
+            self.m_user_bias, self.m_item_bias = g(ctx.get_array(USER, ARR_BIAS)), ctx.get_array(ITEM, ARR_BIAS)
+            arrays += [(USER, ARR_BIAS, self.m_user_bias), (ITEM, ARR_BIAS, self.m_item_bias)]
         self._V_theta = self._V_beta = None
+        if self._comm is not None:
+            self._finish_sharded(arrays)
 
     def fit(self, train_df, val_df=None, global_mean=0.0):
         cfg = self.config
@@ -68,23 +75,23 @@ class GaussianHost(DeviceModel):
         self._initialize_variational_params()
         u, i, x = frame_arrays(train_df)
         ctx = self._open_context(u, i, x)
-        ctx.set_array(USER, ARR_FACTOR, self.m_theta)
+        ctx.set_array(USER, ARR_FACTOR, self._mine(self.m_theta))
         ctx.set_array(ITEM, ARR_FACTOR, self.m_beta)
         ctx.set_cov_identity(USER, 1.0)
         ctx.set_cov_identity(ITEM, 1.0)
         if self._uses_bias:
-            ctx.set_array(USER, ARR_BIAS, self.m_user_bias)
+            ctx.set_array(USER, ARR_BIAS, self._mine(self.m_user_bias))
             ctx.set_array(ITEM, ARR_BIAS, self.m_item_bias)
+        stats_item = stats_bias = None
+        if self._comm is not None:
+            stats_item, stats_bias = pdist.gauss_stats(ctx, self._device_obj())
         monitor = self._monitor_setup(val_df, offset=global_mean, drop_unseen=True)
         previous = None
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
-            ctx.gauss_factor_sweep(USER, cfg.sigma2, cfg.eta_theta2)
-            ctx.gauss_factor_sweep(ITEM, cfg.sigma2, cfg.eta_beta2)
-            if self._uses_bias:
-                ctx.gauss_bias_sweep(USER, cfg.sigma2, cfg.eta_bias2)
-                ctx.gauss_bias_sweep(ITEM, cfg.sigma2, cfg.eta_bias2)
+            pdist.gaussian_iteration(ctx, self._comm, stats_item, stats_bias, cfg.sigma2, cfg.eta_theta2,
+                                     cfg.eta_beta2, cfg.eta_bias2 if self._uses_bias else None)
             self._tick(it)
             if monitor is None:
                 continue

@@ -24,5 +24,5 @@ class GaussianMFCAVI(GaussianHost):
     """r_ij ~ N(mu + theta_i . beta_j, sigma2)."""
     _uses_bias = False
 
-    def __init__(self, config: GaussianMFCAVIConfig, dtype=None, device=None):
-        super().__init__(config, dtype, device)
+    def __init__(self, config: GaussianMFCAVIConfig, dtype=None, device=None, comm=None):
+        super().__init__(config, dtype, device, comm)

@@ -12,7 +12,7 @@ import numpy as np
 
 from src.evaluation.metrics import macro_mae, rmse
 from src.models._device_model import ITEM, USER, DeviceModel, frame_arrays
-from pmf_hip import ARR_FACTOR, ARR_HYPER_RATE, ARR_PRIOR_RATE, ARR_RATE, ARR_SHAPE
+from pmf_hip import ARR_FACTOR, ARR_HYPER_RATE, ARR_PRIOR_RATE, ARR_RATE, ARR_SHAPE, dist as pdist
 
 
 @dataclass
@@ -34,8 +34,8 @@ class HPF_CAVI(DeviceModel):
     """x_ui ~ Poisson(theta_u . beta_i); theta_uk ~ Gamma(a, xi_u), xi_u ~ Gamma(a', b');
     beta_ik ~ Gamma(c, eta_i), eta_i ~ Gamma(c', d')."""
 
-    def __init__(self, config: HPF_CAVI_Config, dtype=None, device=None):
-        super().__init__(config, dtype, device)
+    def __init__(self, config: HPF_CAVI_Config, dtype=None, device=None, comm=None):
+        super().__init__(config, dtype, device, comm)
         self.gamma_a_theta = self.gamma_b_theta = None
         self.gamma_a_beta = self.gamma_b_beta = None
         self.gamma_a_xi = self.gamma_b_xi = None
@@ -65,12 +65,14 @@ class HPF_CAVI(DeviceModel):
         self.E_eta = self.gamma_a_eta / self.gamma_b_eta
 
     def _pull_state(self):
-        ctx = self._ctx
-        self.gamma_a_theta, self.gamma_b_theta = ctx.get_array(USER, ARR_SHAPE), ctx.get_array(USER, ARR_RATE)
+        ctx, g = self._ctx, self._gather_users
+        self.gamma_a_theta, self.gamma_b_theta = g(ctx.get_array(USER, ARR_SHAPE)), g(ctx.get_array(USER, ARR_RATE))
         self.gamma_a_beta, self.gamma_b_beta = ctx.get_array(ITEM, ARR_SHAPE), ctx.get_array(ITEM, ARR_RATE)
-        self.E_theta, self.E_beta = ctx.get_array(USER, ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
-        self.gamma_b_xi, self.gamma_b_eta = ctx.get_array(USER, ARR_HYPER_RATE), ctx.get_array(ITEM, ARR_HYPER_RATE)
-        self.E_xi, self.E_eta = ctx.get_array(USER, ARR_PRIOR_RATE), ctx.get_array(ITEM, ARR_PRIOR_RATE)
+        self.E_theta, self.E_beta = g(ctx.get_array(USER, ARR_FACTOR)), ctx.get_array(ITEM, ARR_FACTOR)
+        self.gamma_b_xi, self.gamma_b_eta = g(ctx.get_array(USER, ARR_HYPER_RATE)), ctx.get_array(ITEM, ARR_HYPER_RATE)
+        self.E_xi, self.E_eta = g(ctx.get_array(USER, ARR_PRIOR_RATE)), ctx.get_array(ITEM, ARR_PRIOR_RATE)
+        if self._comm is not None:
+            self._finish_sharded([(USER, ARR_FACTOR, self.E_theta), (ITEM, ARR_FACTOR, self.E_beta)])
 
     def fit(self, train_df, val_df=None):
         cfg = self.config
@@ -78,18 +80,20 @@ class HPF_CAVI(DeviceModel):
         self._initialize()
         u, i, x = frame_arrays(train_df)
         ctx = self._open_context(u, i, x)
-        ctx.set_array(USER, ARR_FACTOR, self.E_theta)
+        ctx.set_array(USER, ARR_FACTOR, self._mine(self.E_theta))
         ctx.set_array(ITEM, ARR_FACTOR, self.E_beta)
-        ctx.set_array(USER, ARR_PRIOR_RATE, self.E_xi)
+        ctx.set_array(USER, ARR_PRIOR_RATE, self._mine(self.E_xi))
         ctx.set_array(ITEM, ARR_PRIOR_RATE, self.E_eta)
+        stats = pdist.gamma_stats(ctx, self._device_obj()) if self._comm is not None else None
+        user_prior = (cfg.a, 0.0, True, self.gamma_a_xi, cfg.b_prime)
+        item_prior = (cfg.c, 0.0, True, self.gamma_a_eta, cfg.d_prime)
         monitor = self._monitor_setup(val_df)
         previous = None
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
                 print(f"\nHPF_CAVI iteration {it}/{cfg.max_iter}")
             # theta then xi (hpf_cavi.py:126-159); beta then eta (hpf_cavi.py:162-193)
-            ctx.gamma_sweep(USER, cfg.a, 0.0, True, self.gamma_a_xi, cfg.b_prime)
-            ctx.gamma_sweep(ITEM, cfg.c, 0.0, True, self.gamma_a_eta, cfg.d_prime)
+            pdist.gamma_iteration(ctx, self._comm, stats, user_prior, item_prior)
             self._tick(it)
             if monitor is None:
                 continue

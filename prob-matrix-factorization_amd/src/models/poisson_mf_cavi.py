@@ -12,7 +12,7 @@ import numpy as np
 
 from src.evaluation.metrics import macro_mae, rmse
 from src.models._device_model import ITEM, USER, DeviceModel, frame_arrays
-from pmf_hip import ARR_FACTOR, ARR_RATE, ARR_SHAPE
+from pmf_hip import ARR_FACTOR, ARR_RATE, ARR_SHAPE, dist as pdist
 
 
 @dataclass
@@ -29,8 +29,8 @@ class PoissonMFCAVIConfig:
 class PoissonMFCAVI(DeviceModel):
     """x_ij ~ Poisson(theta_i . beta_j), theta, beta ~ Gamma(a0, b0)."""
 
-    def __init__(self, config: PoissonMFCAVIConfig, dtype=None, device=None):
-        super().__init__(config, dtype, device)
+    def __init__(self, config: PoissonMFCAVIConfig, dtype=None, device=None, comm=None):
+        super().__init__(config, dtype, device, comm)
         self.a_theta = self.b_theta = self.a_beta = self.b_beta = None
         self.E_theta = self.E_beta = None
 
@@ -46,10 +46,12 @@ class PoissonMFCAVI(DeviceModel):
         self.E_beta = self.a_beta / self.b_beta
 
     def _pull_state(self):
-        ctx = self._ctx
-        self.a_theta, self.b_theta = ctx.get_array(USER, ARR_SHAPE), ctx.get_array(USER, ARR_RATE)
+        ctx, g = self._ctx, self._gather_users
+        self.a_theta, self.b_theta = g(ctx.get_array(USER, ARR_SHAPE)), g(ctx.get_array(USER, ARR_RATE))
         self.a_beta, self.b_beta = ctx.get_array(ITEM, ARR_SHAPE), ctx.get_array(ITEM, ARR_RATE)
-        self.E_theta, self.E_beta = ctx.get_array(USER, ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
+        self.E_theta, self.E_beta = g(ctx.get_array(USER, ARR_FACTOR)), ctx.get_array(ITEM, ARR_FACTOR)
+        if self._comm is not None:
+            self._finish_sharded([(USER, ARR_FACTOR, self.E_theta), (ITEM, ARR_FACTOR, self.E_beta)])
 
     def fit(self, train_df, val_df=None):
         cfg = self.config
@@ -57,15 +59,18 @@ class PoissonMFCAVI(DeviceModel):
         self._initialize_variational_params()
         u, i, x = frame_arrays(train_df)
         ctx = self._open_context(u, i, x)
-        ctx.set_array(USER, ARR_FACTOR, self.E_theta)
+        ctx.set_array(USER, ARR_FACTOR, self._mine(self.E_theta))
         ctx.set_array(ITEM, ARR_FACTOR, self.E_beta)
+        stats = pdist.gamma_stats(ctx, self._device_obj()) if self._comm is not None else None
+        prior = (cfg.a0, cfg.b0, False, 0.0, 0.0)
         monitor = self._monitor_setup(val_df)
         previous = None
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
-            ctx.gamma_sweep(USER, cfg.a0, cfg.b0)   # poisson_mf_cavi.py:135-170
-            ctx.gamma_sweep(ITEM, cfg.a0, cfg.b0)   # poisson_mf_cavi.py:173-200
+            # users (poisson_mf_cavi.py:135-170) then items (:173-200); with a Comm the item
+            # half-sweep is accumulate -> all-reduce -> finalize
+            pdist.gamma_iteration(ctx, self._comm, stats, prior, prior)
             self._tick(it)
             if monitor is None:
                 continue

@@ -39,7 +39,6 @@ def test_hpf_logical_shards_equal_single_context(K, dtype, tol):
 
     def new_ctx(n_users, uu, ii, xx, lo, hi):
         c = pmf_hip.Context(n_users, I, K, dtype=dtype)
-        c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.set_ratings(uu, ii, xx)
         c.set_array(USER, ARR_FACTOR, st["E_theta"][lo:hi]); c.set_array(ITEM, ARR_FACTOR, st["E_beta"])
         c.set_array(USER, ARR_PRIOR_RATE, st["E_xi"][lo:hi]); c.set_array(ITEM, ARR_PRIOR_RATE, st["E_eta"])
@@ -82,7 +81,6 @@ def test_gaussian_logical_shards_equal_single_context(K, dtype, tol):
 
     def new_ctx(n_users, uu, ii, xx, lo, hi):
         c = pmf_hip.Context(n_users, I, K, dtype=dtype)
-        c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.set_ratings(uu, ii, xx)
         c.set_array(USER, ARR_FACTOR, st["m_theta"][lo:hi]); c.set_array(ITEM, ARR_FACTOR, st["m_beta"])
         c.set_cov_identity(USER); c.set_cov_identity(ITEM)

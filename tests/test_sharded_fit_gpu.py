@@ -1,0 +1,119 @@
+"""User-sharded multi-process `fit` of the model classes: two ranks (gloo, both on
+the one GPU of the test box) must reproduce the single-process fit -- factors,
+validation trajectory, stop iteration -- and leave predict() working on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data():
+    sys.path[:0] = [os.path.join(ROOT, "prob-matrix-factorization_amd")]
+    from pmf_hip.synth import synth_ratings, train_val_split
+    u, i, r = synth_ratings(3000, 400, 60000, seed=21)
+    u[0], i[0] = 2999, 399
+    (tu, ti, tr), (vu, vi, vr) = train_val_split(u, i, r)
+    tu[0], ti[0] = 2999, 399
+    train = pd.DataFrame({"u": tu, "i": ti, "rating": tr})
+    val = pd.DataFrame({"u": np.append(vu, 3005), "i": np.append(vi, 7), "rating": np.append(vr, 4.0)})
+    return train, val
+
+
+def _build(kind, comm=None):
+    if kind == "hpf":
+        from src.models.hpf_cavi import HPF_CAVI, HPF_CAVI_Config
+        return HPF_CAVI(HPF_CAVI_Config(n_factors=12, a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0,
+                                        max_iter=12, tol=1e-3, verbose=False), dtype="f64", comm=comm), \
+            ("E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_theta", "gamma_b_beta")
+    if kind == "poisson":
+        from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
+        return PoissonMFCAVI(PoissonMFCAVIConfig(n_factors=12, a0=0.1, b0=0.5, max_iter=6, tol=None, verbose=False),
+                             dtype="f64", comm=comm), ("E_theta", "E_beta", "a_theta", "b_beta")
+    from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
+    return GaussianMFCAVI(GaussianMFCAVIConfig(n_factors=12, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0,
+                                               max_iter=5, tol=-1.0, verbose=False), dtype="f64", comm=comm), \
+        ("m_theta", "m_beta", "m_user_bias", "m_item_bias")
+
+
+def _fit(kind, model, train, val):
+    if kind == "gauss":
+        gm = float(train["rating"].mean())
+        a, b = train.copy(), val.copy()
+        a["rating"] -= gm; b["rating"] -= gm
+        model.fit(a, val_df=b, global_mean=gm)
+        return model.predict(val["u"].to_numpy(), val["i"].to_numpy(), gm)
+    if kind == "hpf":
+        a, b = train.copy(), val.copy()
+        a["rating"] += 1; b["rating"] += 1
+        model.fit(a, val_df=b)
+    else:
+        model.fit(train, val_df=val)
+    return model.predict(val["u"].to_numpy(), val["i"].to_numpy())
+
+
+def _worker(rank, world, port, kind, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as tdist
+    from pmf_hip import dist as pdist
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    train, val = _data()
+    model, keys = _build(kind, comm=pdist.Comm())
+    pred = _fit(kind, model, train, val)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pred=pred, val_rmse=np.array(model.history_["val_rmse"]),
+             iters=model.history_["iterations"], **{k: getattr(model, k) for k in keys})
+    if kind == "gauss":
+        np.save(os.path.join(out_dir, f"V{rank}.npy"), model.V_theta[::97])
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["hpf", "poisson", "gauss"])
+def test_two_rank_fit_matches_single_process(kind, tmp_path):
+    import torch.multiprocessing as mp
+    train, val = _data()
+    model, keys = _build(kind)
+    pred = _fit(kind, model, train, val)
+    mp.spawn(_worker, args=(2, _free_port(), kind, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert int(d["iters"]) == model.history_["iterations"]
+        np.testing.assert_allclose(d["val_rmse"], model.history_["val_rmse"], rtol=1e-10)
+        for k in keys:
+            np.testing.assert_allclose(d[k], getattr(model, k), rtol=1e-9, atol=1e-11, err_msg=k)
+        np.testing.assert_allclose(d["pred"], pred, rtol=1e-9, atol=1e-11)
+        if kind == "gauss":
+            np.testing.assert_allclose(np.load(os.path.join(tmp_path, f"V{rank}.npy")), model.V_theta[::97],
+                                       rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("workload", ["gaussian_mf", "hpf_cavi"])
+def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload):
+    """bench.py launched as the driver launches it (torch.distributed.run, 2 ranks; gloo and one
+    shared GPU stand in for RCCL over two): the replicated item state must end bit-identical on
+    both ranks, i.e. kernels and collectives are ordered on the shared stream."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--small",
+           "--backend", "gloo", "--share-gpu", "--only", "--workload", workload]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["item_replicas_identical"] is True

@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--only", action="store_true", help="skip the secondary HPF-CAVI measurement of the default run")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a single-GPU box)")
+    ap.add_argument("--chunks", type=int, default=None, help="item row chunks of the pipelined item half-sweep at "
+                    "N > 1 (default PMF_DIST_CHUNKS or 4; 1 = accumulate, then all-reduce, then finalize)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0")
     ap.add_argument("--factors", type=int, default=None, help="exploration: override the workload's K")
     args = ap.parse_args()
@@ -207,6 +209,8 @@ def main():
         ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
         # kernels, RCCL collectives and torch allocations share one non-default stream
         scope = pdist.StreamScope(ctx, device).enter()
+        if comm is not None:
+            ctx.set_row_chunks(ITEM, args.chunks or pdist.default_item_chunks(world))
         rng = np.random.default_rng(42)
         t0 = time.time()
         if gauss:
@@ -322,7 +326,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": w["label"] + (" [--small]" if args.small else ""), "n_users_per_gpu": U,
                    "n_items": I, "ratings_per_gpu": N, "n_factors": K,
-                   "parallelism": f"user-range rating shards x{world}, item statistics all-reduce (RCCL)"
+                   "parallelism": f"user-range rating shards x{world}, item statistics all-reduce ({args.backend}) "
+                                  f"pipelined over {args.chunks or pdist.default_item_chunks(world)} item chunks"
                                   if world > 1 else "single GPU",
                    "epoch_algorithmic_GB": main_res["epoch_algorithmic_GB"],
                    "epoch_fraction_of_hbm_roofline": main_res["epoch_fraction_of_hbm_roofline"]},

@@ -106,6 +106,16 @@ int pmf_ctx_destroy(pmf_ctx *ctx);
  * through a non-default stream (pmf_hip/dist.py:StreamScope). */
 int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream);
 int pmf_ctx_sync(pmf_ctx *ctx);
+
+/* Row chunks (no reference counterpart; multi-GPU pipelining).  `n_chunks` equal row ranges of
+ * one side; the *_accumulate / *_finalize calls of that side then act on the chunk chosen with
+ * pmf_ctx_select_chunk (-1 = all rows, the default) -- they read and write only rows
+ * [row_begin, row_end) of the statistics buffer, at the same offsets as in an unchunked call,
+ * so a caller can all-reduce the slice of chunk c while chunk c+1 is being accumulated.
+ * The fused *_sweep calls always cover all rows.  Results do not depend on the chunking. */
+int pmf_ctx_set_row_chunks(pmf_ctx *ctx, int side, int n_chunks);
+int pmf_ctx_chunk_rows(pmf_ctx *ctx, int side, int chunk, int64_t *row_begin, int64_t *row_end);
+int pmf_ctx_select_chunk(pmf_ctx *ctx, int side, int chunk);
 /* bytes of device memory currently held by the context */
 int pmf_ctx_device_bytes(pmf_ctx *ctx, int64_t *bytes);
 

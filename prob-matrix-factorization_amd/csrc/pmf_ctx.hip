@@ -195,6 +195,8 @@ static void free_index(pmf_ctx *ctx) {
         ix.d_nonempty = nullptr;
         ix.n_nonempty = 0;
         ix.h_ptr.clear();
+        ix.h_nonempty.clear();
+        ix.nonempty_off.clear();
         free_tasks(ctx, ix.gamma_tasks);
         free_tasks(ctx, ix.gauss_tasks);
         free_tasks(ctx, ix.bias_tasks);
@@ -278,8 +280,14 @@ extern "C" int pmf_ctx_cov_stride(pmf_ctx *ctx, int *stride) {
 // Tasks are emitted longest-first so that the lane groups of one wavefront
 // (which each take one task) carry similar amounts of work and the grid's tail
 // consists of short tasks.
+//
+// With row chunks (pmf_ctx_set_row_chunks) the tasks are grouped by the chunk of
+// their row -- longest-first inside every group -- and `task_off` / `split_off`
+// hold the group boundaries (the split list is in row order, hence grouped too).
 static void build_tasks(const std::vector<int64_t> &ptr, int64_t rows, int chunk, bool keep_empty,
-                        std::vector<PmfTask> &tasks, std::vector<PmfSplitRow> &split, int64_t &n_slots) {
+                        const std::vector<int64_t> &row_bounds, std::vector<PmfTask> &tasks,
+                        std::vector<PmfSplitRow> &split, int64_t &n_slots, std::vector<int64_t> &task_off,
+                        std::vector<int64_t> &split_off) {
     std::vector<PmfTask> raw;
     raw.reserve((size_t)rows + 1024);
     n_slots = 0;
@@ -300,20 +308,77 @@ static void build_tasks(const std::vector<int64_t> &ptr, int64_t rows, int chunk
         }
         n_slots += q;
     }
-    // counting sort by length, descending, stable
-    std::vector<int64_t> bucket((size_t)chunk + 2, 0);
-    for (const PmfTask &t : raw) bucket[(size_t)(chunk - t.len) + 1]++;
+    // counting sort by (row chunk, length descending), stable; `raw` is in row order
+    const size_t n_groups = row_bounds.size() - 1, span = (size_t)chunk + 1;
+    std::vector<int64_t> bucket(n_groups * span + 1, 0);
+    std::vector<int32_t> group(raw.size());
+    {
+        size_t g = 0;
+        for (size_t k = 0; k < raw.size(); ++k) {
+            while (raw[k].row >= row_bounds[g + 1]) ++g;
+            group[k] = (int32_t)g;
+            bucket[g * span + (size_t)(chunk - raw[k].len) + 1]++;
+        }
+    }
     for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
+    task_off.resize(n_groups + 1);
+    for (size_t g = 0; g <= n_groups; ++g) task_off[g] = bucket[g * span];
     tasks.resize(raw.size());
-    for (const PmfTask &t : raw) tasks[(size_t)bucket[(size_t)(chunk - t.len)]++] = t;
+    for (size_t k = 0; k < raw.size(); ++k)
+        tasks[(size_t)bucket[(size_t)group[k] * span + (size_t)(chunk - raw[k].len)]++] = raw[k];
+    split_off.assign(n_groups + 1, (int64_t)split.size());
+    {
+        size_t k = 0;
+        for (size_t g = 0; g < n_groups; ++g) {
+            while (k < split.size() && split[k].row < row_bounds[g]) ++k;
+            split_off[g] = (int64_t)k;
+        }
+    }
 }
 
-static int upload_tasks(pmf_ctx *ctx, const std::vector<int64_t> &ptr, int64_t rows, int chunk,
+static std::vector<int64_t> chunk_bounds(const pmf_ctx *ctx, int side) {
+    std::vector<int64_t> b((size_t)ctx->n_chunks[side] + 1);
+    for (int c = 0; c <= ctx->n_chunks[side]; ++c) b[(size_t)c] = pmf_chunk_row0(ctx, side, c);
+    return b;
+}
+
+PmfTaskView pmf_task_view(const pmf_ctx *ctx, int side, const PmfTaskList &tl, bool select) {
+    const PmfSideIndex &ix = ctx->index[side];
+    const int c = select ? ctx->cur_chunk[side] : -1;
+    PmfTaskView v;
+    v.n_slots = tl.n_slots;
+    if (c < 0 || tl.task_off.empty()) {
+        v.d_tasks = tl.d_tasks;
+        v.d_split = tl.d_split;
+        v.d_split_rows = tl.d_split_rows;
+        v.n_tasks = tl.n_tasks;
+        v.n_split = tl.n_split;
+        v.row0 = 0;
+        v.row1 = ctx->rows[side];
+        v.d_nonempty = ix.d_nonempty;
+        v.n_nonempty = ix.n_nonempty;
+        return v;
+    }
+    const size_t g = (size_t)c;
+    v.d_tasks = tl.d_tasks + tl.task_off[g];
+    v.n_tasks = tl.task_off[g + 1] - tl.task_off[g];
+    v.d_split = tl.d_split + tl.split_off[g];
+    v.d_split_rows = tl.d_split_rows + tl.split_off[g];
+    v.n_split = tl.split_off[g + 1] - tl.split_off[g];
+    v.row0 = pmf_chunk_row0(ctx, side, c);
+    v.row1 = pmf_chunk_row0(ctx, side, c + 1);
+    v.d_nonempty = ix.d_nonempty + ix.nonempty_off[g];
+    v.n_nonempty = ix.nonempty_off[g + 1] - ix.nonempty_off[g];
+    return v;
+}
+
+static int upload_tasks(pmf_ctx *ctx, int side, const std::vector<int64_t> &ptr, int64_t rows, int chunk,
                         bool keep_empty, PmfTaskList &out) {
     std::vector<PmfTask> tasks;
     std::vector<PmfSplitRow> split;
     int64_t n_slots = 0;
-    build_tasks(ptr, rows, chunk, keep_empty, tasks, split, n_slots);
+    build_tasks(ptr, rows, chunk, keep_empty, chunk_bounds(ctx, side), tasks, split, n_slots, out.task_off,
+                out.split_off);
     out.n_tasks = (int64_t)tasks.size();
     out.n_split = (int64_t)split.size();
     out.n_slots = n_slots;
@@ -332,6 +397,25 @@ static int upload_tasks(pmf_ctx *ctx, const std::vector<int64_t> &ptr, int64_t r
         for (size_t k = 0; k < split.size(); ++k) ids[k] = split[k].row;
         PMF_HIP_CHECK(hipMemcpy(out.d_split_rows, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    return PMF_OK;
+}
+
+// (re)build the three task lists of one side for the current row chunking
+static int build_work_lists(pmf_ctx *ctx, int side) {
+    PmfSideIndex &ix = ctx->index[side];
+    const int64_t rows = ctx->rows[side];
+    free_tasks(ctx, ix.gamma_tasks);
+    free_tasks(ctx, ix.gauss_tasks);
+    free_tasks(ctx, ix.bias_tasks);
+    const std::vector<int64_t> bounds = chunk_bounds(ctx, side);
+    ix.nonempty_off.assign(bounds.size(), (int64_t)ix.h_nonempty.size());
+    for (size_t g = 0; g + 1 < bounds.size(); ++g)
+        ix.nonempty_off[g] = std::lower_bound(ix.h_nonempty.begin(), ix.h_nonempty.end(), (int32_t)bounds[g]) -
+                             ix.h_nonempty.begin();
+    int rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAMMA_CHUNK, true, ix.gamma_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAUSS_CHUNK, false, ix.gauss_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAMMA_CHUNK, false, ix.bias_tasks))) return rc;
     return PMF_OK;
 }
 
@@ -412,10 +496,56 @@ static int set_ratings_impl(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, 
         if ((rc = pmf_dev_alloc(ctx, (void **)&ix.d_nonempty, nonempty.size() * sizeof(int32_t)))) return rc;
         if (!nonempty.empty())
             PMF_HIP_CHECK(hipMemcpy(ix.d_nonempty, nonempty.data(), nonempty.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        if ((rc = upload_tasks(ctx, ix.h_ptr, rows, PMF_GAMMA_CHUNK, true, ix.gamma_tasks))) return rc;
-        if ((rc = upload_tasks(ctx, ix.h_ptr, rows, PMF_GAUSS_CHUNK, false, ix.gauss_tasks))) return rc;
-        if ((rc = upload_tasks(ctx, ix.h_ptr, rows, PMF_GAMMA_CHUNK, false, ix.bias_tasks))) return rc;
+        ix.h_nonempty.swap(nonempty);
+        if ((rc = build_work_lists(ctx, side))) return rc;
     }
+    return PMF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// row chunks: a half-sweep split into row ranges so that a multi-GPU caller can
+// all-reduce the statistics of one range while the next one is being accumulated
+// ---------------------------------------------------------------------------
+static int set_row_chunks_impl(pmf_ctx *ctx, int side, int n_chunks) {
+    CHECK_CTX(ctx, "pmf_ctx_set_row_chunks");
+    PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, "pmf_ctx_set_row_chunks: bad side %d", side);
+    PMF_REQUIRE(n_chunks >= 1 && n_chunks <= 1024, PMF_EINVAL,
+                "pmf_ctx_set_row_chunks: n_chunks = %d outside [1, 1024]", n_chunks);
+    if ((int64_t)n_chunks > ctx->rows[side]) n_chunks = (int)(ctx->rows[side] > 0 ? ctx->rows[side] : 1);
+    PMF_HIP_CHECK(hipSetDevice(ctx->device));
+    PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_chunks[side] = n_chunks;
+    ctx->cur_chunk[side] = -1;
+    if (ctx->index[side].d_ptr) return build_work_lists(ctx, side);
+    return PMF_OK;
+}
+
+extern "C" int pmf_ctx_set_row_chunks(pmf_ctx *ctx, int side, int n_chunks) {
+    try {
+        return set_row_chunks_impl(ctx, side, n_chunks);
+    } catch (const std::bad_alloc &) {
+        pmf_set_error("pmf_ctx_set_row_chunks: out of host memory");
+        return PMF_ENOMEM;
+    }
+}
+
+extern "C" int pmf_ctx_chunk_rows(pmf_ctx *ctx, int side, int chunk, int64_t *row_begin, int64_t *row_end) {
+    CHECK_CTX(ctx, "pmf_ctx_chunk_rows");
+    PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, "pmf_ctx_chunk_rows: bad side %d", side);
+    PMF_REQUIRE(row_begin && row_end, PMF_EINVAL, "pmf_ctx_chunk_rows: null argument");
+    PMF_REQUIRE(chunk >= 0 && chunk < ctx->n_chunks[side], PMF_ERANGE,
+                "pmf_ctx_chunk_rows: chunk %d outside [0, %d)", chunk, ctx->n_chunks[side]);
+    *row_begin = pmf_chunk_row0(ctx, side, chunk);
+    *row_end = pmf_chunk_row0(ctx, side, chunk + 1);
+    return PMF_OK;
+}
+
+extern "C" int pmf_ctx_select_chunk(pmf_ctx *ctx, int side, int chunk) {
+    CHECK_CTX(ctx, "pmf_ctx_select_chunk");
+    PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, "pmf_ctx_select_chunk: bad side %d", side);
+    PMF_REQUIRE(chunk >= -1 && chunk < ctx->n_chunks[side], PMF_ERANGE,
+                "pmf_ctx_select_chunk: chunk %d outside [-1, %d)", chunk, ctx->n_chunks[side]);
+    ctx->cur_chunk[side] = chunk;
     return PMF_OK;
 }
 

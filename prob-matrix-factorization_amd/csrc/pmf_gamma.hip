@@ -36,7 +36,8 @@ struct GammaParams {
     T shape_prior, rate_prior, hyper_shape, hyper_rate_prior;
     int hierarchical;
     int K, kpad;
-    int64_t rows;
+    int64_t row0;       // first row of a finalize-from-stats launch
+    int64_t rows;       // one past its last row
 };
 
 // shape = prior + sum, rate = prior_rate + sum, E = shape / rate, plus the
@@ -228,7 +229,7 @@ template <typename T, int LPR>
 __global__ __launch_bounds__(256) void gamma_finalize_all_kernel(GammaParams<T> p) {
     constexpr int G = 256 / LPR;
     const int c = threadIdx.x % LPR;
-    const int64_t row = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
+    const int64_t row = p.row0 + (int64_t)blockIdx.x * G + threadIdx.x / LPR;
     if (row >= p.rows) return;
     const int koff = c * PMF_VEC;
     const bool active = koff < p.kpad;
@@ -245,9 +246,9 @@ __global__ __launch_bounds__(256) void gamma_finalize_all_kernel(GammaParams<T> 
 // host side
 // ---------------------------------------------------------------------------
 template <typename T, int LPR>
-static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, int mode /*0 fused, 1 accumulate, 2 finalize, 3 extended*/) {
+static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, const PmfTaskView &tl,
+                        int mode /*0 fused, 1 accumulate, 2 finalize, 3 extended*/) {
     constexpr int G = 256 / LPR;
-    const PmfTaskList &tl = ctx->index[side].gamma_tasks;
     if (mode != 2) {
         if (tl.n_tasks > 0) {
             PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_SWEEP);
@@ -271,8 +272,10 @@ static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, int mode /*0 
         }
     } else {
         PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_FINAL);
-        dim3 grid((unsigned)((p.rows + G - 1) / G));
-        hipLaunchKernelGGL((gamma_finalize_all_kernel<T, LPR>), grid, dim3(256), 0, ctx->stream, p);
+        if (p.rows > p.row0) {
+            dim3 grid((unsigned)((p.rows - p.row0 + G - 1) / G));
+            hipLaunchKernelGGL((gamma_finalize_all_kernel<T, LPR>), grid, dim3(256), 0, ctx->stream, p);
+        }
     }
     PMF_HIP_CHECK(hipGetLastError());
     return PMF_OK;
@@ -283,7 +286,7 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
                      int hierarchical, double hyper_shape, double hyper_rate_prior) {
     const int other = 1 - side;
     const PmfSideIndex &ix = ctx->index[side];
-    const PmfTaskList &tl = ix.gamma_tasks;
+    const PmfTaskView tl = pmf_task_view(ctx, side, ix.gamma_tasks, mode == 1 || mode == 2);
     int rc;
     if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gamma_sweep"))) return rc;
     if ((rc = pmf_require_array(ctx, other, PMF_ARR_FACTOR, "pmf_gamma_sweep"))) return rc;
@@ -332,16 +335,17 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
     p.hierarchical = hierarchical;
     p.K = ctx->K;
     p.kpad = ctx->kpad;
-    p.rows = ctx->rows[side];
+    p.row0 = tl.row0;   // finalize-from-stats covers rows [row0, rows)
+    p.rows = tl.row1;
 
     switch (pmf_lanes_per_row(ctx->kpad)) {
-        case 1: return launch_gamma<T, 1>(ctx, side, p, mode);
-        case 2: return launch_gamma<T, 2>(ctx, side, p, mode);
-        case 4: return launch_gamma<T, 4>(ctx, side, p, mode);
-        case 8: return launch_gamma<T, 8>(ctx, side, p, mode);
-        case 16: return launch_gamma<T, 16>(ctx, side, p, mode);
-        case 32: return launch_gamma<T, 32>(ctx, side, p, mode);
-        case 64: return launch_gamma<T, 64>(ctx, side, p, mode);
+        case 1: return launch_gamma<T, 1>(ctx, side, p, tl, mode);
+        case 2: return launch_gamma<T, 2>(ctx, side, p, tl, mode);
+        case 4: return launch_gamma<T, 4>(ctx, side, p, tl, mode);
+        case 8: return launch_gamma<T, 8>(ctx, side, p, tl, mode);
+        case 16: return launch_gamma<T, 16>(ctx, side, p, tl, mode);
+        case 32: return launch_gamma<T, 32>(ctx, side, p, tl, mode);
+        case 64: return launch_gamma<T, 64>(ctx, side, p, tl, mode);
     }
     pmf_set_error("pmf_gamma_sweep: unsupported n_factors %d", ctx->K);
     return PMF_ERANGE;

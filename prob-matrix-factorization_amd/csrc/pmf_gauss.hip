@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
 
 template <typename T>
 struct SolveParams {
-    const int32_t *rows;  // list of rows to solve, or null = every row (skip rows with S == 0)
+    const int32_t *rows;  // list of rows to solve, or null = rows row0 .. row0 + n (skip rows with S == 0)
+    int64_t row0;
     int64_t n;
     const T *src_s;
     int64_t src_s_stride;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
     if (idx >= p.n) return;
-    const int row = p.rows ? rfl(p.rows[idx]) : (int)idx;
+    const int row = p.rows ? rfl(p.rows[idx]) : (int)(p.row0 + idx);
     const T *S = p.src_s + (int64_t)row * p.src_s_stride;
     if (!p.rows && S[0] == (T)0) return;  // no rating anywhere for this row
     T *img = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * p.cov_stride;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
     float *xbuf = img + PAIR_IMG, *gbuf = xbuf + 512, *wbuf = gbuf + 128;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t idx = blockIdx.x;
-    const int row = p.rows ? p.rows[idx] : (int)idx;
+    const int row = p.rows ? p.rows[idx] : (int)(p.row0 + idx);
     const float *S = p.src_s + (int64_t)row * p.src_s_stride;
     if (!p.rows && S[0] == 0.f) return;  // uniform for the whole block
     const int K = p.K, j = 64 * wave + lane;
@@ -776,7 +777,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gauss_solve_lds_kernel(SolveParams<T> p) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int64_t idx = blockIdx.x;
-    const int row = p.rows ? p.rows[idx] : (int)idx;
+    const int row = p.rows ? p.rows[idx] : (int)(p.row0 + idx);
     const T *S = p.src_s + (int64_t)row * p.src_s_stride;
     if (!p.rows && S[0] == (T)0) return;
     const int K = p.K, ld = K + 1;
@@ -854,7 +855,7 @@ struct BiasParams {
     T *stats;    // [rows][2] (residual sum, count), STATS mode
     T inv_sigma2, inv_eta_bias2;
     int kpad;
-    int64_t rows;
+    int64_t row0, rows;  // finalize-from-stats covers rows [row0, rows)
 };
 
 template <typename T>
@@ -940,7 +941,7 @@ __global__ void gauss_bias_split_kernel(BiasParams<T> p, int64_t n_split, const 
 
 template <typename T>
 __global__ void gauss_bias_finalize_all_kernel(BiasParams<T> p) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = p.row0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.rows) return;
     const T cnt = p.stats[r * 2 + 1];
     if (cnt > (T)0) p.bias_self[r] = bias_from_sum(p, p.stats[r * 2], cnt);
@@ -1001,7 +1002,7 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
     *fused = false;
     const int other = 1 - side;
     const PmfSideIndex &ix = ctx->index[side];
-    const PmfTaskList &tl = ix.gauss_tasks;
+    const PmfTaskView tl = pmf_task_view(ctx, side, ix.gauss_tasks, stats != nullptr);
     int rc;
     PMF_REQUIRE(ix.d_ptr, PMF_EINVAL, "pmf_gauss_factor_sweep: ratings have not been set");
     if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gauss_factor_sweep"))) return rc;
@@ -1024,7 +1025,9 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
     p.bias_other = bias ? (const T *)ctx->arr[other][PMF_ARR_BIAS] : nullptr;
     p.partial = (T *)ctx->d_partial;
     if (stats) {
-        PMF_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)ctx->rows[side] * width * sizeof(T), ctx->stream));
+        if (tl.row1 > tl.row0)  // rows without ratings on this rank contribute zeros
+            PMF_HIP_CHECK(hipMemsetAsync((T *)stats + tl.row0 * width, 0, (size_t)(tl.row1 - tl.row0) * width * sizeof(T),
+                                         ctx->stream));
         p.dst_s = (T *)stats;
         p.dst_s_stride = width;
         p.dst_w = (T *)stats + ctx->cov_stride;
@@ -1092,16 +1095,19 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     if ((rc = pmf_require_array(ctx, side, PMF_ARR_COV, "pmf_gauss_factor_finalize"))) return rc;
     SolveParams<T> sp;
     const int width = ctx->cov_stride + ctx->kpad;
+    const PmfTaskView tl = pmf_task_view(ctx, side, ix.gauss_tasks, stats != nullptr);
     if (stats) {
         sp.rows = nullptr;
-        sp.n = ctx->rows[side];
+        sp.row0 = tl.row0;
+        sp.n = tl.row1 - tl.row0;
         sp.src_s = (const T *)stats;
         sp.src_s_stride = width;
         sp.src_w = (const T *)stats + ctx->cov_stride;
         sp.src_w_stride = width;
     } else {
-        sp.rows = split_rows_only ? ix.gauss_tasks.d_split_rows : ix.d_nonempty;
-        sp.n = split_rows_only ? ix.gauss_tasks.n_split : ix.n_nonempty;
+        sp.rows = split_rows_only ? tl.d_split_rows : tl.d_nonempty;
+        sp.row0 = 0;
+        sp.n = split_rows_only ? tl.n_split : tl.n_nonempty;
         sp.src_s = (const T *)ctx->arr[side][PMF_ARR_COV];
         sp.src_s_stride = ctx->cov_stride;
         sp.src_w = (const T *)ctx->arr[side][PMF_ARR_FACTOR];
@@ -1183,7 +1189,7 @@ template <typename T>
 static int run_bias(pmf_ctx *ctx, int side, int mode, void *stats, double sigma2, double eta_bias2) {
     const int other = 1 - side;
     const PmfSideIndex &ix = ctx->index[side];
-    const PmfTaskList &tl = ix.bias_tasks;
+    const PmfTaskView tl = pmf_task_view(ctx, side, ix.bias_tasks, mode != 0);
     int rc;
     PMF_REQUIRE(ix.d_ptr, PMF_EINVAL, "pmf_gauss_bias_sweep: ratings have not been set");
     if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gauss_bias_sweep"))) return rc;
@@ -1208,16 +1214,19 @@ static int run_bias(pmf_ctx *ctx, int side, int mode, void *stats, double sigma2
     p.inv_sigma2 = mode == 1 ? (T)1 : (T)(1.0 / sigma2);
     p.inv_eta_bias2 = mode == 1 ? (T)1 : (T)(1.0 / eta_bias2);
     p.kpad = ctx->kpad;
-    p.rows = ctx->rows[side];
+    p.row0 = tl.row0;
+    p.rows = tl.row1;
     PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_BIAS);
     if (mode == 2) {
-        dim3 grid((unsigned)((p.rows + 255) / 256));
-        hipLaunchKernelGGL((gauss_bias_finalize_all_kernel<T>), grid, dim3(256), 0, ctx->stream, p);
+        if (p.rows > p.row0) {
+            dim3 grid((unsigned)((p.rows - p.row0 + 255) / 256));
+            hipLaunchKernelGGL((gauss_bias_finalize_all_kernel<T>), grid, dim3(256), 0, ctx->stream, p);
+        }
         PMF_HIP_CHECK(hipGetLastError());
         return PMF_OK;
     }
-    if (mode == 1)
-        PMF_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)p.rows * 2 * sizeof(T), ctx->stream));
+    if (mode == 1 && p.rows > p.row0)
+        PMF_HIP_CHECK(hipMemsetAsync((T *)stats + p.row0 * 2, 0, (size_t)(p.rows - p.row0) * 2 * sizeof(T), ctx->stream));
     if (tl.n_tasks > 0) {
         switch (pmf_lanes_per_row(ctx->kpad)) {
             case 1: launch_bias<T, 1>(ctx, p, mode == 1); break;

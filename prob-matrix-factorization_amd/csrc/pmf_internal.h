@@ -62,6 +62,20 @@ struct PmfTaskList {
     PmfTask *d_tasks = nullptr;
     PmfSplitRow *d_split = nullptr;
     int32_t *d_split_rows = nullptr;  // row id of every split row (solve list)
+    // row chunks (pmf_ctx_set_row_chunks): tasks are grouped by the chunk of their row,
+    // longest-first inside each group; [n_chunks + 1] offsets into d_tasks / d_split
+    std::vector<int64_t> task_off, split_off;
+};
+
+// The part of a task list (and of the row range) one accumulate / finalize call covers.
+struct PmfTaskView {
+    const PmfTask *d_tasks = nullptr;
+    const PmfSplitRow *d_split = nullptr;
+    const int32_t *d_split_rows = nullptr;
+    int64_t n_tasks = 0, n_split = 0, n_slots = 0;
+    int64_t row0 = 0, row1 = 0;            // row range [row0, row1)
+    const int32_t *d_nonempty = nullptr;   // rows of the range with at least one rating
+    int64_t n_nonempty = 0;
 };
 
 // Ratings ordered by one side (CSR when side = user, CSC when side = item).
@@ -72,6 +86,8 @@ struct PmfSideIndex {
     std::vector<int64_t> h_ptr;  // host copy of ptr (task building)
     int32_t *d_nonempty = nullptr;  // rows with at least one rating (Gaussian solve list)
     int64_t n_nonempty = 0;
+    std::vector<int32_t> h_nonempty;    // host copy of d_nonempty
+    std::vector<int64_t> nonempty_off;  // [n_chunks + 1] offsets into d_nonempty
     PmfTaskList gamma_tasks;     // chunk = PMF_GAMMA_CHUNK, empty rows included
     PmfTaskList gauss_tasks;     // chunk = PMF_GAUSS_CHUNK, empty rows excluded
     PmfTaskList bias_tasks;      // chunk = PMF_GAMMA_CHUNK, empty rows excluded
@@ -98,6 +114,9 @@ struct pmf_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     size_t elem = 4;
+
+    int n_chunks[2] = {1, 1};    // row chunks per side (multi-GPU pipelining of a half-sweep)
+    int cur_chunk[2] = {-1, -1};  // chunk the accumulate / finalize calls act on; -1 = all rows
 
     void *arr[2][PMF_ARR_COUNT] = {};
     PmfSideIndex index[2];
@@ -126,6 +145,13 @@ struct pmf_ctx {
 
 #define PMF_GAMMA_CHUNK 256
 #define PMF_GAUSS_CHUNK 512
+
+// first row of chunk c of a side (c = n_chunks gives the row count)
+static inline int64_t pmf_chunk_row0(const pmf_ctx *ctx, int side, int c) {
+    return ctx->rows[side] * (int64_t)c / ctx->n_chunks[side];
+}
+// `select` = honour pmf_ctx_select_chunk (accumulate / finalize); fused sweeps pass false
+PmfTaskView pmf_task_view(const pmf_ctx *ctx, int side, const PmfTaskList &tl, bool select);
 
 int pmf_dev_alloc(pmf_ctx *ctx, void **p, size_t bytes);
 void pmf_dev_free(pmf_ctx *ctx, void *p, size_t bytes);

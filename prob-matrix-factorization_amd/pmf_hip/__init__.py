@@ -47,6 +47,9 @@ SIGNATURES = {
     "pmf_ctx_destroy": (C.c_int, [_p]),
     "pmf_ctx_set_stream": (C.c_int, [_p, _p]),
     "pmf_ctx_sync": (C.c_int, [_p]),
+    "pmf_ctx_set_row_chunks": (C.c_int, [_p, C.c_int, C.c_int]),
+    "pmf_ctx_chunk_rows": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pmf_ctx_select_chunk": (C.c_int, [_p, C.c_int, C.c_int]),
     "pmf_ctx_device_bytes": (C.c_int, [_p, _i64p]),
     "pmf_ctx_set_ratings": (C.c_int, [_p, C.c_int64, _i32p, _i32p, _f64p]),
     "pmf_set_array": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),

@@ -38,6 +38,10 @@ class Comm:
         self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
         return tensor
 
+    def all_reduce_async(self, tensor):
+        """Returns the work handle; `.wait()` orders the current stream after the collective."""
+        return self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def barrier(self):
         self._dist.barrier(group=self.group)
 
@@ -67,6 +71,33 @@ def take_shard(user_ids, item_ids, ratings, bounds, rank):
 
 
 # ---- one iteration per model ------------------------------------------------
+def _item_half_sweep(engine, comm, stats, width, accumulate, finalize):
+    """accumulate -> all-reduce -> finalize over the item rows.  When the engine has item row
+    chunks (`set_row_chunks(ITEM, n)`, the same n on every rank) the three stages are pipelined:
+    the statistics of chunk c travel (asynchronous all-reduce on the collective's own stream)
+    while chunk c+1 is accumulated, and chunk c is finalised while later chunks still travel.
+    The arithmetic per row is that of the unchunked call, so results do not depend on n."""
+    n = getattr(engine, "n_chunks", {}).get(ITEM, 1)
+    if n <= 1:
+        accumulate()
+        comm.all_reduce(stats.tensor)
+        finalize()
+        return
+    works = []
+    try:
+        for c in range(n):
+            engine.select_chunk(ITEM, c)
+            accumulate()
+            lo, hi = engine.chunk_rows(ITEM, c)
+            works.append(comm.all_reduce_async(stats.tensor[lo * width:hi * width]))
+        for c in range(n):
+            works[c].wait()
+            engine.select_chunk(ITEM, c)
+            finalize()
+    finally:
+        engine.select_chunk(ITEM, -1)
+
+
 def gamma_iteration(engine, comm, stats_item, user_prior, item_prior):
     """Poisson MF / HPF.  `*_prior` = (shape_prior, rate_prior, hierarchical,
     hyper_shape, hyper_rate_prior) as taken by `gamma_sweep`.
@@ -75,9 +106,9 @@ def gamma_iteration(engine, comm, stats_item, user_prior, item_prior):
     if comm is None or comm.world == 1:
         engine.gamma_sweep(ITEM, *item_prior)
         return
-    engine.gamma_accumulate(ITEM, stats_item.ptr)
-    comm.all_reduce(stats_item.tensor)
-    engine.gamma_finalize(ITEM, stats_item.ptr, *item_prior)
+    _item_half_sweep(engine, comm, stats_item, 2 * engine.kpad,
+                     lambda: engine.gamma_accumulate(ITEM, stats_item.ptr),
+                     lambda: engine.gamma_finalize(ITEM, stats_item.ptr, *item_prior))
 
 
 def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2, eta_beta2,
@@ -89,15 +120,16 @@ def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2,
     if single:
         engine.gauss_factor_sweep(ITEM, sigma2, eta_beta2)
     else:
-        engine.gauss_factor_accumulate(ITEM, stats_item.ptr)
-        comm.all_reduce(stats_item.tensor)
-        engine.gauss_factor_finalize(ITEM, stats_item.ptr, sigma2, eta_beta2)
+        _item_half_sweep(engine, comm, stats_item, engine.cov_stride + engine.kpad,
+                         lambda: engine.gauss_factor_accumulate(ITEM, stats_item.ptr),
+                         lambda: engine.gauss_factor_finalize(ITEM, stats_item.ptr, sigma2, eta_beta2))
     if eta_bias2 is None:
         return
     engine.gauss_bias_sweep(USER, sigma2, eta_bias2)
     if single:
         engine.gauss_bias_sweep(ITEM, sigma2, eta_bias2)
     else:
+        # [I x 2]: latency-bound, one message (chunk selection is -1 = all rows here)
         engine.gauss_bias_accumulate(ITEM, stats_bias.ptr)
         comm.all_reduce(stats_bias.tensor)
         engine.gauss_bias_finalize(ITEM, stats_bias.ptr, sigma2, eta_bias2)
@@ -148,6 +180,14 @@ class DeviceStats:
         tdt = torch.float64 if np_dtype == np.float64 else torch.float32
         self.tensor = torch.zeros(int(n_elems), dtype=tdt, device=device)
         self.ptr = self.tensor.data_ptr()
+
+
+def default_item_chunks(world):
+    """Item row chunks of a sharded run: PMF_DIST_CHUNKS, else 4 (1 = no pipelining)."""
+    import os
+    if world <= 1:
+        return 1
+    return max(1, int(os.environ.get("PMF_DIST_CHUNKS", "4")))
 
 
 def gamma_stats(ctx, device):

@@ -29,6 +29,24 @@ class Context:
         check(self._lib.pmf_ctx_cov_stride(self._h, C.byref(k)), "pmf_ctx_cov_stride")
         self.cov_stride = k.value
         self.nnz = 0
+        self.n_chunks = {USER: 1, ITEM: 1}
+
+    # ---- row chunks (multi-GPU pipelining of a half-sweep) --------------
+    def set_row_chunks(self, side, n_chunks):
+        """Split `side`'s rows into equal ranges; accumulate / finalize calls then act on the
+        range chosen with `select_chunk` (-1 = all rows)."""
+        n = max(1, min(int(n_chunks), self.rows(side), 1024))
+        check(self._lib.pmf_ctx_set_row_chunks(self._h, side, n), "pmf_ctx_set_row_chunks")
+        self.n_chunks[side] = n
+
+    def chunk_rows(self, side, chunk):
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        check(self._lib.pmf_ctx_chunk_rows(self._h, side, int(chunk), C.byref(lo), C.byref(hi)),
+              "pmf_ctx_chunk_rows")
+        return lo.value, hi.value
+
+    def select_chunk(self, side, chunk):
+        check(self._lib.pmf_ctx_select_chunk(self._h, side, int(chunk)), "pmf_ctx_select_chunk")
 
     # ---- lifetime -------------------------------------------------------
     def close(self):

@@ -85,6 +85,7 @@ class DeviceModel:
             torch.cuda.set_device(self._device)
             self._exit_stream()
             self._scope = pdist.StreamScope(self._ctx, self._device_obj()).enter()
+            self._ctx.set_row_chunks(pmf_hip.ITEM, pdist.default_item_chunks(self._comm.world))
         self._ctx.set_ratings(u, i, x)
         import time
         self._t_last = time.perf_counter()

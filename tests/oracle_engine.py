@@ -25,6 +25,39 @@ class OracleEngine:
         self.u, self.i, self.x = np.asarray(u, np.int64), np.asarray(i, np.int64), np.asarray(x, np.float64)
         self.idx = (orc.group_positions(self.u, n_users), orc.group_positions(self.i, n_items))
         self.st = {}
+        self.n_chunks = {USER: 1, ITEM: 1}
+        self._cur = {USER: -1, ITEM: -1}
+
+    # --- row chunks (same contract as pmf_ctx_set_row_chunks / select_chunk) ---
+    def _rows(self, side):
+        return self.n_users if side == USER else self.n_items
+
+    def set_row_chunks(self, side, n):
+        self.n_chunks[side] = max(1, min(int(n), self._rows(side)))
+
+    def chunk_rows(self, side, c):
+        r, n = self._rows(side), self.n_chunks[side]
+        return r * c // n, r * (c + 1) // n
+
+    def select_chunk(self, side, c):
+        assert -1 <= c < self.n_chunks[side]
+        self._cur[side] = c
+
+    def _window(self, side):
+        return (0, self._rows(side)) if self._cur[side] < 0 else self.chunk_rows(side, self._cur[side])
+
+    def _put(self, side, stats, block):
+        """write rows [lo, hi) of `block` ([rows, width]) into the flat stats buffer"""
+        lo, hi = self._window(side)
+        w = block.shape[1]
+        stats[lo * w:hi * w] = block[lo:hi].reshape(-1)
+
+    def _merge(self, side, key, new):
+        """take rows [lo, hi) of a finalize result, keep the rest of the state"""
+        lo, hi = self._window(side)
+        out = self.st[key].copy()
+        out[lo:hi] = new[lo:hi]
+        return out
 
     # --- helpers ---------------------------------------------------------
     def _sides(self, side):
@@ -44,12 +77,14 @@ class OracleEngine:
         pr = "E_xi" if side == USER else "E_eta"
         hr = "gamma_b_xi" if side == USER else "gamma_b_eta"
         rp = self.st[pr][:, None] if hier else rate_prior
-        self.st[f"a_{s}"] = shape_prior + a
-        self.st[f"b_{s}"] = rp + b
-        self.st[f"E_{s}"] = self.st[f"a_{s}"] / self.st[f"b_{s}"]
+        new_a, new_b = shape_prior + a, rp + b
+        new_E = new_a / new_b
+        for key, val in ((f"a_{s}", new_a), (f"b_{s}", new_b), (f"E_{s}", new_E)):
+            self.st[key] = self._merge(side, key, val) if key in self.st else val
         if hier:
-            self.st[hr] = hyper_rate_prior + self.st[f"E_{s}"].sum(axis=1)
-            self.st[pr] = hyper_shape / self.st[hr]
+            new_hr = hyper_rate_prior + new_E.sum(axis=1)
+            self.st[hr] = self._merge(side, hr, new_hr) if hr in self.st else new_hr
+            self.st[pr] = self._merge(side, pr, hyper_shape / new_hr)
 
     def gamma_sweep(self, side, *prior):
         a, b = self._gamma_sums(side)
@@ -57,7 +92,7 @@ class OracleEngine:
 
     def gamma_accumulate(self, side, stats):
         a, b = self._gamma_sums(side)
-        stats[:] = np.stack([a, b], axis=1).reshape(-1)
+        self._put(side, stats, np.stack([a, b], axis=1).reshape(a.shape[0], -1))
 
     def gamma_finalize(self, side, stats, *prior):
         rows = self.n_users if side == USER else self.n_items
@@ -83,6 +118,9 @@ class OracleEngine:
         K = self.K
         S = S.reshape(-1, K, K)
         live = S[:, 0, 0] != 0
+        lo, hi = self._window(side)
+        live[:lo] = False
+        live[hi:] = False
         V = np.linalg.inv(S[live] / sigma2 + np.eye(K) / eta2)
         self.st[f"V_{me}"] = self.st[f"V_{me}"].copy()
         self.st[f"m_{me}"] = self.st[f"m_{me}"].copy()
@@ -95,7 +133,7 @@ class OracleEngine:
 
     def gauss_factor_accumulate(self, side, stats):
         S, w = self._gauss_sums(side)
-        stats[:] = np.concatenate([S, w], axis=1).reshape(-1)
+        self._put(side, stats, np.concatenate([S, w], axis=1))
 
     def gauss_factor_finalize(self, side, stats, sigma2, eta2):
         rows = self.n_users if side == USER else self.n_items
@@ -116,6 +154,9 @@ class OracleEngine:
         key = "m_user_bias" if side == USER else "m_item_bias"
         out = self.st[key].copy()
         nz = cnt > 0
+        lo, hi = self._window(side)
+        nz[:lo] = False
+        nz[hi:] = False
         var = 1.0 / (1.0 / eta_bias2 + cnt[nz] / sigma2)
         out[nz] = var / sigma2 * tot[nz]
         self.st[key] = out
@@ -125,7 +166,7 @@ class OracleEngine:
 
     def gauss_bias_accumulate(self, side, stats):
         tot, cnt = self._bias_sums(side)
-        stats[:] = np.stack([tot, cnt], axis=1).reshape(-1)
+        self._put(side, stats, np.stack([tot, cnt], axis=1))
 
     def gauss_bias_finalize(self, side, stats, sigma2, eta_bias2):
         rows = self.n_users if side == USER else self.n_items

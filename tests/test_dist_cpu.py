@@ -22,7 +22,7 @@ def _problem():
     return skewed_problem(11, 400, 60, 6000, rating_kind="count")
 
 
-def _worker(rank, world, port, kind, out_dir):
+def _worker(rank, world, port, kind, out_dir, chunks=1):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as tdist
@@ -37,6 +37,7 @@ def _worker(rank, world, port, kind, out_dir):
     lu, li, lx = pdist.take_shard(u, i, x, bounds, rank)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     eng = OracleEngine(hi - lo, I, K, lu, li, lx)
+    eng.set_row_chunks(1, chunks)  # item side: pipelined accumulate / all-reduce / finalize
     if kind == "hpf":
         st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, seed=1)
         eng.st = {"E_theta": st["E_theta"][lo:hi], "E_beta": st["E_beta"], "E_xi": st["E_xi"][lo:hi],
@@ -63,12 +64,13 @@ def _worker(rank, world, port, kind, out_dir):
     tdist.destroy_process_group()
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
 @pytest.mark.parametrize("kind", ["hpf", "gauss"])
-def test_two_rank_sharded_iteration_matches_unsharded_oracle(kind, tmp_path):
+def test_two_rank_sharded_iteration_matches_unsharded_oracle(kind, chunks, tmp_path):
     import torch.multiprocessing as mp
     from oracle import cavi_oracle as orc
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), chunks), nprocs=world, join=True)
     u, i, x = _problem()
     U, I, K = 400, 60, 6
     idx = (orc.group_positions(u, U), orc.group_positions(i, I))

@@ -99,8 +99,8 @@ def test_two_rank_fit_matches_single_process(kind, tmp_path):
                                        rtol=1e-8, atol=1e-11)
 
 
-@pytest.mark.parametrize("workload", ["gaussian_mf", "hpf_cavi"])
-def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload):
+@pytest.mark.parametrize("workload,chunks", [("gaussian_mf", 4), ("hpf_cavi", 4), ("gaussian_mf", 1)])
+def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload, chunks):
     """bench.py launched as the driver launches it (torch.distributed.run, 2 ranks; gloo and one
     shared GPU stand in for RCCL over two): the replicated item state must end bit-identical on
     both ranks, i.e. kernels and collectives are ordered on the shared stream."""
@@ -110,7 +110,7 @@ def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--small",
-           "--backend", "gloo", "--share-gpu", "--only", "--workload", workload]
+           "--backend", "gloo", "--share-gpu", "--only", "--workload", workload, "--chunks", str(chunks)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

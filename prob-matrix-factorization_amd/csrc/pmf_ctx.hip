@@ -1,6 +1,8 @@
 // Context lifecycle, rating upload (stable CSR/CSC build + work lists), model
 // state exchange and profiling for libpmf_hip.so.
+#include <limits.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -435,6 +437,50 @@ extern "C" int pmf_ctx_set_ratings(pmf_ctx *ctx, int64_t nnz, const int32_t *use
     }
 }
 
+// Host build of one side (stable counting sort).  Used for nnz >= 2^31 - 1 and with
+// PMF_INDEX_HOST=1 (the tests compare it with the device build of pmf_index.hip).
+static int fill_side_host(pmf_ctx *ctx, int side, int64_t nnz, const int32_t *key, const int32_t *oth,
+                          const double *ratings, std::vector<int32_t> &other, std::vector<char> &val) {
+    const int64_t rows = ctx->rows[side];
+    PmfSideIndex &ix = ctx->index[side];
+    ix.h_ptr.assign((size_t)rows + 1, 0);
+    for (int64_t n = 0; n < nnz; ++n) ix.h_ptr[(size_t)key[n] + 1]++;
+    for (int64_t r = 0; r < rows; ++r) ix.h_ptr[(size_t)r + 1] += ix.h_ptr[(size_t)r];
+    std::vector<int64_t> cursor(ix.h_ptr.begin(), ix.h_ptr.end() - 1);
+    if (ctx->dtype == PMF_F64) {
+        double *v = (double *)val.data();
+        for (int64_t n = 0; n < nnz; ++n) {
+            int64_t d = cursor[(size_t)key[n]]++;
+            other[(size_t)d] = oth[n];
+            v[d] = ratings[n];
+        }
+    } else {
+        float *v = (float *)val.data();
+        for (int64_t n = 0; n < nnz; ++n) {
+            int64_t d = cursor[(size_t)key[n]]++;
+            other[(size_t)d] = oth[n];
+            v[d] = (float)ratings[n];
+        }
+    }
+    PMF_HIP_CHECK(hipMemcpy(ix.d_ptr, ix.h_ptr.data(), (size_t)(rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (nnz) {
+        PMF_HIP_CHECK(hipMemcpy(ix.d_other, other.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        PMF_HIP_CHECK(hipMemcpy(ix.d_val, val.data(), (size_t)nnz * ctx->elem, hipMemcpyHostToDevice));
+    }
+    return PMF_OK;
+}
+
+static int bad_id_error(const pmf_ctx *ctx, const int32_t *user_ids, const int32_t *item_ids, int64_t n) {
+    const int64_t U = ctx->rows[0], I = ctx->rows[1];
+    PMF_REQUIRE(user_ids[n] >= 0 && user_ids[n] < U, PMF_ERANGE,
+                "pmf_ctx_set_ratings: user id %d at position %lld outside [0, %lld)", user_ids[n], (long long)n,
+                (long long)U);
+    PMF_REQUIRE(item_ids[n] >= 0 && item_ids[n] < I, PMF_ERANGE,
+                "pmf_ctx_set_ratings: item id %d at position %lld outside [0, %lld)", item_ids[n], (long long)n,
+                (long long)I);
+    return PMF_OK;
+}
+
 static int set_ratings_impl(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, const int32_t *item_ids,
                             const double *ratings) {
     CHECK_CTX(ctx, "pmf_ctx_set_ratings");
@@ -443,52 +489,42 @@ static int set_ratings_impl(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, 
                 "pmf_ctx_set_ratings: null input array");
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
     PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int64_t U = ctx->rows[0], I = ctx->rows[1];
-    for (int64_t n = 0; n < nnz; ++n) {
-        PMF_REQUIRE(user_ids[n] >= 0 && user_ids[n] < U, PMF_ERANGE,
-                    "pmf_ctx_set_ratings: user id %d at position %lld outside [0, %lld)", user_ids[n],
-                    (long long)n, (long long)U);
-        PMF_REQUIRE(item_ids[n] >= 0 && item_ids[n] < I, PMF_ERANGE,
-                    "pmf_ctx_set_ratings: item id %d at position %lld outside [0, %lld)", item_ids[n],
-                    (long long)n, (long long)I);
+    // positions are sorted as 32-bit values on the device
+    const bool on_host = nnz >= (int64_t)INT32_MAX || getenv("PMF_INDEX_HOST") != nullptr;
+    int rc;
+    PmfIndexBuild *build = nullptr;
+    // validation comes first: a bad id leaves the context's previous ratings in place
+    if (on_host) {
+        for (int64_t n = 0; n < nnz; ++n)
+            if ((rc = bad_id_error(ctx, user_ids, item_ids, n))) return rc;
+    } else {
+        int64_t bad = -1;
+        if ((rc = pmf_index_device_begin(ctx, nnz, user_ids, item_ids, ratings, &build, &bad))) return rc;
+        if (bad >= 0) return bad_id_error(ctx, user_ids, item_ids, bad);
     }
     free_index(ctx);
     ctx->nnz = nnz;
-    std::vector<int32_t> other((size_t)nnz);
-    std::vector<char> val((size_t)nnz * ctx->elem);
     for (int side = 0; side < 2; ++side) {
-        const int32_t *key = side == PMF_SIDE_USER ? user_ids : item_ids;
-        const int32_t *oth = side == PMF_SIDE_USER ? item_ids : user_ids;
+        PmfSideIndex &ix = ctx->index[side];
+        rc = pmf_dev_alloc(ctx, (void **)&ix.d_ptr, (size_t)(ctx->rows[side] + 1) * sizeof(int64_t));
+        if (!rc) rc = pmf_dev_alloc(ctx, (void **)&ix.d_other, (size_t)nnz * sizeof(int32_t));
+        if (!rc) rc = pmf_dev_alloc(ctx, &ix.d_val, (size_t)nnz * ctx->elem);
+        if (rc) {
+            pmf_index_device_abort(build);
+            return rc;
+        }
+    }
+    if (on_host) {
+        std::vector<int32_t> other((size_t)nnz);
+        std::vector<char> val((size_t)nnz * ctx->elem);
+        if ((rc = fill_side_host(ctx, PMF_SIDE_USER, nnz, user_ids, item_ids, ratings, other, val))) return rc;
+        if ((rc = fill_side_host(ctx, PMF_SIDE_ITEM, nnz, item_ids, user_ids, ratings, other, val))) return rc;
+    } else {
+        if ((rc = pmf_index_device_finish(ctx, build, nnz))) return rc;  // consumes `build`
+    }
+    for (int side = 0; side < 2; ++side) {
         const int64_t rows = ctx->rows[side];
         PmfSideIndex &ix = ctx->index[side];
-        ix.h_ptr.assign((size_t)rows + 1, 0);
-        for (int64_t n = 0; n < nnz; ++n) ix.h_ptr[(size_t)key[n] + 1]++;
-        for (int64_t r = 0; r < rows; ++r) ix.h_ptr[(size_t)r + 1] += ix.h_ptr[(size_t)r];
-        std::vector<int64_t> cursor(ix.h_ptr.begin(), ix.h_ptr.end() - 1);
-        if (ctx->dtype == PMF_F64) {
-            double *v = (double *)val.data();
-            for (int64_t n = 0; n < nnz; ++n) {
-                int64_t d = cursor[(size_t)key[n]]++;
-                other[(size_t)d] = oth[n];
-                v[d] = ratings[n];
-            }
-        } else {
-            float *v = (float *)val.data();
-            for (int64_t n = 0; n < nnz; ++n) {
-                int64_t d = cursor[(size_t)key[n]]++;
-                other[(size_t)d] = oth[n];
-                v[d] = (float)ratings[n];
-            }
-        }
-        int rc;
-        if ((rc = pmf_dev_alloc(ctx, (void **)&ix.d_ptr, (size_t)(rows + 1) * sizeof(int64_t)))) return rc;
-        if ((rc = pmf_dev_alloc(ctx, (void **)&ix.d_other, (size_t)nnz * sizeof(int32_t)))) return rc;
-        if ((rc = pmf_dev_alloc(ctx, &ix.d_val, (size_t)nnz * ctx->elem))) return rc;
-        PMF_HIP_CHECK(hipMemcpy(ix.d_ptr, ix.h_ptr.data(), (size_t)(rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-        if (nnz) {
-            PMF_HIP_CHECK(hipMemcpy(ix.d_other, other.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-            PMF_HIP_CHECK(hipMemcpy(ix.d_val, val.data(), (size_t)nnz * ctx->elem, hipMemcpyHostToDevice));
-        }
         std::vector<int32_t> nonempty;
         for (int64_t r = 0; r < rows; ++r)
             if (ix.h_ptr[(size_t)r + 1] > ix.h_ptr[(size_t)r]) nonempty.push_back((int32_t)r);

@@ -162,6 +162,13 @@ size_t pmf_array_elems(const pmf_ctx *ctx, int side, int array);  // device elem
 int pmf_require_array(pmf_ctx *ctx, int side, int array, const char *what);
 int pmf_alloc_array(pmf_ctx *ctx, int side, int array);  // no-op if present (zero-filled)
 
+// device-side index build (pmf_index.hip)
+struct PmfIndexBuild;
+int pmf_index_device_begin(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, const int32_t *item_ids,
+                           const double *ratings, PmfIndexBuild **out, int64_t *bad_position);
+void pmf_index_device_abort(PmfIndexBuild *b);
+int pmf_index_device_finish(pmf_ctx *ctx, PmfIndexBuild *b, int64_t nnz);
+
 // profiling brackets
 void pmf_prof_begin(pmf_ctx *ctx, int kernel);
 void pmf_prof_end(pmf_ctx *ctx);

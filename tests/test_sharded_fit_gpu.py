@@ -117,3 +117,63 @@ def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload, chunks
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["scaling"] == "weak"
     assert res["config"]["item_replicas_identical"] is True
+
+
+def test_pipelined_item_sweep_over_rccl_single_rank():
+    """The one-GPU box cannot hold two RCCL ranks, but it can run the real backend with one:
+    the pipelined item half-sweep (asynchronous all-reduce of statistic slices on RCCL's stream,
+    stream-ordered waits) must give exactly what the same path gives without a collective."""
+    import torch
+    import torch.distributed as tdist
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER, dist as pdist
+    from pmf_hip.synth import synth_ratings
+
+    class Identity:           # same call sequence, no collective
+        world = 2
+
+        def all_reduce(self, t):
+            return t
+
+        def all_reduce_async(self, t):
+            class Done:
+                def wait(self):
+                    pass
+            return Done()
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                             device_id=dev)
+    try:
+        comm = pdist.Comm()
+        comm.world = 2        # take the multi-rank code path; the group itself has one rank
+        U, I, N, K = 20000, 3000, 600000, 64
+        u, i, r = synth_ratings(U, I, N, seed=4)
+        rng = np.random.default_rng(0)
+        m_u, m_i = 0.1 * rng.standard_normal((U, K)), 0.1 * rng.standard_normal((I, K))
+        out = []
+        for c_obj in (comm, Identity()):
+            ctx = pmf_hip.Context(U, I, K)
+            scope = pdist.StreamScope(ctx, dev).enter()
+            ctx.set_row_chunks(ITEM, 4)
+            ctx.set_ratings(u, i, r - r.mean())
+            ctx.set_array(USER, ARR_FACTOR, m_u); ctx.set_array(ITEM, ARR_FACTOR, m_i)
+            ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
+            ctx.set_array(USER, ARR_BIAS, np.zeros(U)); ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
+            s_item, s_bias = pdist.gauss_stats(ctx, dev)
+            for _ in range(3):
+                pdist.gaussian_iteration(ctx, c_obj, s_item, s_bias, 0.5, 1.0, 1.0, 1.0)
+            out.append([ctx.get_array(s, a) for s in (USER, ITEM) for a in (ARR_FACTOR, ARR_COV, ARR_BIAS)])
+            g_item = pdist.gamma_stats(ctx, dev)
+            ctx.set_array(USER, ARR_FACTOR, np.abs(m_u) + 0.1); ctx.set_array(ITEM, ARR_FACTOR, np.abs(m_i) + 0.1)
+            ctx.set_ratings(u, i, r + 1.0)
+            for _ in range(3):
+                pdist.gamma_iteration(ctx, c_obj, g_item, (0.3, 0.3), (0.3, 0.3))
+            out[-1] += [ctx.get_array(s, ARR_FACTOR) for s in (USER, ITEM)]
+            scope.exit()
+            ctx.close()
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+    finally:
+        tdist.destroy_process_group()

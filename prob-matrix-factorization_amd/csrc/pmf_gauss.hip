@@ -433,6 +433,9 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
     for (int s = 0; s < NT; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     float wA = 0.f, wB = 0.f;  // rhs segments 2*wave and 2*wave + 1
 
+    // (fetching the next pair's row ids one trip ahead: 890.3 -> 886.7 ms per C4-shard epoch, i.e.
+    //  nothing; what is left at K = 128 is the row solve -- 320 ms of LDS-return-bound work per epoch
+    //  when run alone, of which ~135 ms are not hidden behind the 754 ms stream)
     for (int j = 0; j < t.len; j += 2) {
         const bool two = j + 1 < t.len;
         const int o0 = col[j], o1 = two ? col[j + 1] : o0;

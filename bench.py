@@ -82,7 +82,7 @@ def cpu_baseline(workload, K, hp, device=0):
         threadpool_limits = None
     gauss = workload.startswith("gaussian_mf")
     if gauss:
-        U, I, N = (12_000, 1_200, 660_000) if K <= 64 else (3_000, 300, 110_000)
+        U, I, N = (20_000, 2_000, 1_100_000) if K <= 64 else (3_000, 300, 110_000)
     else:
         U, I, N = 300_000, 30_000, 16_500_000
     u, i, r = synth_ratings(U, I, N, seed=7)
@@ -219,6 +219,7 @@ def main():
             ctx.set_ratings(u, i, r + 1.0)              # +1 shift as compare_models.py:180-185
         t_csr = time.time() - t0
         stats_item = stats_bias = None
+        t0 = time.time()
         if gauss:
             # gaussian_mf_cavi_bias.py:52-67 initial state
             ctx.set_array(USER, ARR_FACTOR, 0.1 * rng.standard_normal((U, K)))
@@ -250,6 +251,8 @@ def main():
                 pdist.gamma_iteration(ctx, comm, stats_item, up, ip)
             dominant = "gamma_sweep"
 
+        ctx.sync()
+        t_state = time.time() - t0
         for _ in range(warmup):
             step()
         fence()
@@ -267,6 +270,10 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
             elapsed = float(t.item())
+        t0 = time.time()
+        ctx.get_array(USER, ARR_FACTOR)
+        ctx.get_array(ITEM, ARR_FACTOR)
+        t_pull = time.time() - t0
         consistent = None
         if comm is not None:
             # outside the timed region: the replicated item state must be bit-identical on all ranks
@@ -295,7 +302,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n},
             "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
-            "csr_build_and_upload_s": t_csr, "device_GB": ctx.device_bytes() / 1e9,
+            "csr_build_and_upload_s": t_csr, "state_upload_s": t_state, "factor_download_s": t_pull,
+            "device_GB": ctx.device_bytes() / 1e9,
             "item_replicas_identical": consistent,
         }
         scope.exit()
@@ -333,7 +341,10 @@ def main():
                    "epoch_fraction_of_hbm_roofline": main_res["epoch_fraction_of_hbm_roofline"]},
         "roofline": main_res["roofline"],
         "kernels_ms_per_step": main_res["kernels_ms_per_step"],
-        "setup_s": {"generate": t_gen, "csr_build_and_upload": main_res["csr_build_and_upload_s"]},
+        # host-buffer legs of the boundary (never part of `value`): ratings upload + index build,
+        # initial state upload (float64 host arrays), factor means download
+        "setup_s": {"generate": t_gen, "csr_build_and_upload": main_res["csr_build_and_upload_s"],
+                    "state_upload": main_res["state_upload_s"], "factor_download": main_res["factor_download_s"]},
         "device_GB": main_res["device_GB"],
     }
     if world > 1:

@@ -219,11 +219,12 @@ def main():
             ctx.set_ratings(u, i, r + 1.0)              # +1 shift as compare_models.py:180-185
         t_csr = time.time() - t0
         stats_item = stats_bias = None
-        t0 = time.time()
         if gauss:
             # gaussian_mf_cavi_bias.py:52-67 initial state
-            ctx.set_array(USER, ARR_FACTOR, 0.1 * rng.standard_normal((U, K)))
-            ctx.set_array(ITEM, ARR_FACTOR, 0.1 * np.random.default_rng(43).standard_normal((I, K)))
+            init_u, init_i = 0.1 * rng.standard_normal((U, K)), 0.1 * np.random.default_rng(43).standard_normal((I, K))
+            t0 = time.time()
+            ctx.set_array(USER, ARR_FACTOR, init_u)
+            ctx.set_array(ITEM, ARR_FACTOR, init_i)
             ctx.set_cov_identity(USER, 1.0)
             ctx.set_cov_identity(ITEM, 1.0)
             ctx.set_array(USER, ARR_BIAS, np.zeros(U))
@@ -237,9 +238,12 @@ def main():
             dominant = "gauss_accum"
         else:
             # hpf_cavi.py:66-89 initial state
-            ctx.set_array(USER, ARR_FACTOR, (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K))))
+            init_u = (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K)))
             r2 = np.random.default_rng(43)
-            ctx.set_array(ITEM, ARR_FACTOR, (hp["c"] + r2.gamma(1.0, 0.1, (I, K))) / (hp["d_prime"] + r2.gamma(1.0, 0.1, (I, K))))
+            init_i = (hp["c"] + r2.gamma(1.0, 0.1, (I, K))) / (hp["d_prime"] + r2.gamma(1.0, 0.1, (I, K)))
+            t0 = time.time()
+            ctx.set_array(USER, ARR_FACTOR, init_u)
+            ctx.set_array(ITEM, ARR_FACTOR, init_i)
             ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, (hp["a_prime"] + K * hp["a"]) / hp["b_prime"]))
             ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, (hp["c_prime"] + K * hp["c"]) / hp["d_prime"]))
             if comm is not None:

@@ -48,7 +48,11 @@ class Comm:
 
 def shard_bounds(user_ids, n_users, world):
     """User-range boundaries [b_0 = 0, ..., b_world = n_users] balanced by the
-    number of ratings per shard, not by the number of users."""
+    number of ratings per shard, not by the number of users.  Every range holds at
+    least one user (a function of the inputs only, so all ranks agree -- and all
+    ranks raise together when there are fewer users than ranks)."""
+    if n_users < world:
+        raise ValueError(f"cannot shard {n_users} users over {world} ranks")
     counts = np.bincount(np.asarray(user_ids, dtype=np.int64), minlength=n_users)
     cum = np.cumsum(counts)
     total = int(cum[-1]) if len(cum) else 0
@@ -56,7 +60,7 @@ def shard_bounds(user_ids, n_users, world):
     for g in range(1, world):
         target = total * g / world
         b = int(np.searchsorted(cum, target, side="left")) + 1
-        bounds.append(min(max(b, bounds[-1]), n_users))
+        bounds.append(min(max(b, bounds[-1] + 1), n_users - (world - g)))
     bounds.append(n_users)
     return np.asarray(bounds, dtype=np.int64)
 

@@ -75,8 +75,6 @@ class DeviceModel:
             self._bounds = pdist.shard_bounds(u, self.n_users, self._comm.world)
             u, i, x = pdist.take_shard(u, i, x, self._bounds, self._comm.rank)
             n_local = int(self._bounds[self._comm.rank + 1] - self._bounds[self._comm.rank])
-            if n_local <= 0:
-                raise ValueError("a rank received an empty user range: fewer users than ranks")
         self._ctx = pmf_hip.Context(n_local, self.n_items, self.config.n_factors,
                                     dtype=self._dtype, device=self._device)
         if self._comm is not None:

@@ -111,3 +111,15 @@ def test_shard_bounds_balance_ratings_not_rows():
             assert lu.min(initial=0) >= 0 and lu.max(initial=0) < max(b[g + 1] - b[g], 1)
             total += len(lu)
         assert total == len(u)
+
+
+def test_shard_bounds_never_leave_a_rank_without_users():
+    sys.path.insert(0, os.path.join(ROOT, "prob-matrix-factorization_amd"))
+    from pmf_hip import dist as pdist
+    # all ratings on two users at the two ends: rating balance alone would give empty ranges
+    u = np.array([0] * 50 + [9] * 50)
+    for world in (2, 3, 5, 10):
+        b = pdist.shard_bounds(u, 10, world)
+        assert b[0] == 0 and b[-1] == 10 and np.all(np.diff(b) >= 1)
+    with pytest.raises(ValueError):
+        pdist.shard_bounds(u, 10, 11)

@@ -19,24 +19,76 @@ def pick_device(requested="cpu"):
     return torch.device(requested if requested else "cpu")
 
 
-def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=1):
+def _graphed_step(model, optimizer, batch_size, u, i, r):
+    """Capture one full-batch Adam step (loss, backward, update: ~50 small kernels, launch-bound at
+    the reference's sizes) in a HIP graph.  Returns (static index buffer, static loss, graph).
+    The warm-up iterations PyTorch requires before a capture run on throw-away copies of the
+    state, so the captured training is step-for-step the eager one."""
+    dev = r.device
+    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if quiet is not None:   # the side-stream warm-up below is the documented capture recipe
+        quiet(False)
+    saved = [p.detach().clone() for p in model.parameters()]
+    static_idx = torch.arange(batch_size, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            optimizer.zero_grad(set_to_none=True)
+            model.loss(u[static_idx], i[static_idx], r[static_idx]).backward()
+            optimizer.step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    with torch.no_grad():       # undo the warm-up: parameters and Adam moments back to the start
+        for p, q in zip(model.parameters(), saved):
+            p.copy_(q)
+        for st in optimizer.state.values():
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+    graph = torch.cuda.CUDAGraph()
+    optimizer.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        static_loss = model.loss(u[static_idx], i[static_idx], r[static_idx])
+        static_loss.backward()
+        optimizer.step()
+    # the capture itself executed nothing, but be explicit about the starting point
+    return static_idx, static_loss, graph
+
+
+def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=1, graph=None):
     """The reference's external training loop (train_hpf_pytorch_full.py:96-108):
-    Adam over all parameters, shuffled minibatches, one pass per epoch."""
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+    Adam over all parameters, shuffled minibatches, one pass per epoch.
+
+    On a GPU the full-size batches replay one captured HIP graph (`graph=False` or
+    PMF_TORCH_GRAPH=0 keeps the eager loop) and the epoch loss is accumulated on the device
+    (one read-back per epoch instead of one per step)."""
+    import os
+    on_gpu = r.device.type == "cuda"
     n = len(r)
+    if graph is None:
+        graph = os.environ.get("PMF_TORCH_GRAPH", "1") != "0"
+    graph = bool(graph) and on_gpu and n >= batch_size
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr, capturable=graph)
+    if graph:
+        static_idx, static_loss, step_graph = _graphed_step(model, optimizer, batch_size, u, i, r)
     for epoch in range(epochs):
         model.train()
         order = torch.randperm(n, device=r.device)
-        total = 0.0
+        total = torch.zeros((), device=r.device)
         for at in range(0, n, batch_size):
             idx = order[at:at + batch_size]
+            if graph and len(idx) == batch_size:
+                static_idx.copy_(idx)
+                step_graph.replay()
+                total += static_loss
+                continue
             optimizer.zero_grad()
             loss = model.loss(u[idx], i[idx], r[idx])
             loss.backward()
             optimizer.step()
-            total += loss.item()
+            total += loss.detach()
         if verbose and (epoch % log_every == 0 or epoch == epochs - 1):
-            print(f"Epoch {epoch + 1}/{epochs} Loss: {total:.4f}")
+            print(f"Epoch {epoch + 1}/{epochs} Loss: {total.item():.4f}")
     return model
 
 

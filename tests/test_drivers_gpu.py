@@ -144,3 +144,36 @@ def test_engine_first_then_torch_still_sees_the_gpu():
                 os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prob-matrix-factorization_amd")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_hpf_pytorch_graph_replay_trains_like_the_eager_loop():
+    """The HIP-graph captured Adam step (full batches) + eager tail batch against the plain eager
+    loop: same seeds, same shuffles -> same parameters up to the atomic-add order of the
+    embedding gradients; and the graph path must actually be the faster one."""
+    import time
+    import torch
+    from src.experiments.train_hpf_pytorch_full import adam_epochs
+    from src.models.hpf_pytorch import HPF_PyTorch, HPF_PyTorch_Config
+    U, I, N, K = 3000, 2000, 50_000, 10
+    rng = np.random.default_rng(0)
+    un, inn = rng.integers(0, U, N), rng.integers(0, I, N)
+    dev = torch.device("cuda")
+    u, i = torch.from_numpy(un).to(dev), torch.from_numpy(inn).to(dev)
+    r = torch.from_numpy(rng.integers(1, 7, N).astype(np.float32)).to(dev)
+    uc, ic = np.bincount(un, minlength=U), np.bincount(inn, minlength=I)
+    out, secs = [], []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        m = HPF_PyTorch(U, I, uc, ic, HPF_PyTorch_Config(n_factors=K)).to(dev)
+        torch.manual_seed(1)
+        adam_epochs(m, u, i, r, 5e-3, 4096, 1, verbose=False, graph=use_graph)     # includes capture / warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        adam_epochs(m, u, i, r, 5e-3, 4096, 6, verbose=False, graph=use_graph)     # 12 full + 1 tail batch per epoch
+        torch.cuda.synchronize()
+        secs.append(time.perf_counter() - t0)
+        out.append([p.detach().cpu().numpy() for p in m.parameters()])
+    for a, b in zip(*out):
+        assert np.allclose(a, b, rtol=2e-3, atol=2e-4)
+    print(f"eager {secs[0]:.3f} s, graph {secs[1]:.3f} s")
+    assert secs[1] < secs[0]

@@ -135,10 +135,23 @@ def cpu_baseline(workload, K, hp, device=0):
     else:
         pred_cpu = orc.predict_dot(st["E_theta"], st["E_beta"], vu, vi)
     rm_cpu, rm_gpu = orc.rmse(vy, pred_cpu), orc.rmse(vy, pred_gpu)
-    return {"value": N / dt, "unit": "ratings/s", "cores": 1, "kind": "port",
-            "sample": f"1 iteration of the oracle's per-row NumPy loop, {U}x{I}, {N} ratings, K={K} "
-                      f"(same generator), {dt:.1f} s",
-            "val_rmse_cpu": rm_cpu, "val_rmse_gpu_f32": rm_gpu, "val_rmse_abs_diff": abs(rm_cpu - rm_gpu)}
+    out = {"value": N / dt, "unit": "ratings/s", "cores": 1, "kind": "port",
+           "sample": f"1 iteration of the oracle's per-row NumPy loop, {U}x{I}, {N} ratings, K={K} "
+                     f"(same generator), {dt:.1f} s",
+           "val_rmse_cpu": rm_cpu, "val_rmse_gpu_f32": rm_gpu, "val_rmse_abs_diff": abs(rm_cpu - rm_gpu)}
+    if not gauss:
+        # "best-effort CPU" (BASELINE.md section 3): the same iteration as whole-array NumPy
+        # (gather + segment sums, no per-row interpreter loop), a quarter of the sample
+        keep = u < U // 4
+        u4, i4, x4 = u[keep], i[keep], x[keep]
+        st4 = orc.init_hpf(U // 4, I, K, hp["a"], hp["a_prime"], hp["b_prime"], hp["c"], hp["c_prime"], hp["d_prime"], 0)
+        idx4 = (orc.group_positions(u4, U // 4), orc.group_positions(i4, I))
+        t0 = time.perf_counter()
+        orc.hpf_iteration(st4, idx4, u4, i4, x4, hp["a"], hp["b_prime"], hp["c"], hp["d_prime"], orc.gamma_half_sweep_segsum)
+        dv = time.perf_counter() - t0
+        out["vectorised"] = {"value": len(u4) / dv, "unit": "ratings/s",
+                             "sample": f"segment-sum NumPy restatement, {U // 4}x{I}, {len(u4)} ratings, {dv:.1f} s"}
+    return out
 
 
 def main():
@@ -210,7 +223,8 @@ def main():
         # kernels, RCCL collectives and torch allocations share one non-default stream
         scope = pdist.StreamScope(ctx, device).enter()
         if comm is not None:
-            ctx.set_row_chunks(ITEM, args.chunks or pdist.default_item_chunks(world))
+            n_chunks = args.chunks or pdist.default_item_chunks(world, pdist.item_message_bytes(ctx, gauss))
+            ctx.set_row_chunks(ITEM, n_chunks)
         rng = np.random.default_rng(42)
         t0 = time.time()
         if gauss:
@@ -308,7 +322,7 @@ def main():
             "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
             "csr_build_and_upload_s": t_csr, "state_upload_s": t_state, "factor_download_s": t_pull,
             "device_GB": ctx.device_bytes() / 1e9,
-            "item_replicas_identical": consistent,
+            "item_replicas_identical": consistent, "item_chunks": ctx.n_chunks[ITEM],
         }
         scope.exit()
         ctx.close()
@@ -339,7 +353,7 @@ def main():
         "config": {"workload": w["label"] + (" [--small]" if args.small else ""), "n_users_per_gpu": U,
                    "n_items": I, "ratings_per_gpu": N, "n_factors": K,
                    "parallelism": f"user-range rating shards x{world}, item statistics all-reduce ({args.backend}) "
-                                  f"pipelined over {args.chunks or pdist.default_item_chunks(world)} item chunks"
+                                  f"pipelined over {main_res['item_chunks']} item chunks"
                                   if world > 1 else "single GPU",
                    "epoch_algorithmic_GB": main_res["epoch_algorithmic_GB"],
                    "epoch_fraction_of_hbm_roofline": main_res["epoch_fraction_of_hbm_roofline"]},
@@ -360,6 +374,8 @@ def main():
                                     "roofline": also["roofline"]}}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank)
+        if also is not None:
+            out["also"]["hpf_cavi"]["cpu_baseline"] = cpu_baseline("hpf_cavi", K, WORKLOADS["hpf_cavi"]["hp"], local_rank)
     print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()

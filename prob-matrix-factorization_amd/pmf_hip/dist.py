@@ -186,12 +186,23 @@ class DeviceStats:
         self.ptr = self.tensor.data_ptr()
 
 
-def default_item_chunks(world):
-    """Item row chunks of a sharded run: PMF_DIST_CHUNKS, else 4 (1 = no pipelining)."""
+def default_item_chunks(world, message_bytes=0):
+    """Item row chunks of a sharded run.  PMF_DIST_CHUNKS if set; else slices of about 256 MB,
+    at least 4 (so that at most a quarter of the all-reduce is exposed) and at most 32, but never
+    below 4 MB per slice (latency-bound collectives).  1 = no pipelining."""
     import os
     if world <= 1:
         return 1
-    return max(1, int(os.environ.get("PMF_DIST_CHUNKS", "4")))
+    if "PMF_DIST_CHUNKS" in os.environ:
+        return max(1, int(os.environ["PMF_DIST_CHUNKS"]))
+    n = min(max(int(message_bytes) // (256 << 20), 4), 32)
+    return max(1, min(n, max(1, int(message_bytes) // (4 << 20)))) if message_bytes else 4
+
+
+def item_message_bytes(ctx, gaussian):
+    """Bytes of the item statistics one iteration all-reduces (the factor half-sweep's message)."""
+    width = (ctx.cov_stride + ctx.kpad) if gaussian else 2 * ctx.kpad
+    return ctx.n_items * width * np.dtype(ctx.np_dtype).itemsize
 
 
 def gamma_stats(ctx, device):

@@ -38,6 +38,7 @@ class DeviceModel:
     """Base of the four CAVI classes.  Subclasses set `_uses_bias`."""
 
     _uses_bias = False
+    _gaussian = False     # Gaussian models exchange [I x (Kp + Kpad)] statistics, the others [I x 2 Kpad]
 
     def __init__(self, config, dtype=None, device=None, comm=None):
         """`comm`: a `pmf_hip.dist.Comm` (torch.distributed group, one rank per GPU) makes
@@ -83,7 +84,8 @@ class DeviceModel:
             torch.cuda.set_device(self._device)
             self._exit_stream()
             self._scope = pdist.StreamScope(self._ctx, self._device_obj()).enter()
-            self._ctx.set_row_chunks(pmf_hip.ITEM, pdist.default_item_chunks(self._comm.world))
+            self._ctx.set_row_chunks(pmf_hip.ITEM, pdist.default_item_chunks(
+                self._comm.world, pdist.item_message_bytes(self._ctx, self._gaussian)))
         self._ctx.set_ratings(u, i, x)
         import time
         self._t_last = time.perf_counter()

@@ -23,6 +23,7 @@ class GaussianMFCAVIConfig:
 class GaussianMFCAVI(GaussianHost):
     """r_ij ~ N(mu + theta_i . beta_j, sigma2)."""
     _uses_bias = False
+    _gaussian = True
 
     def __init__(self, config: GaussianMFCAVIConfig, dtype=None, device=None, comm=None):
         super().__init__(config, dtype, device, comm)

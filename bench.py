@@ -302,6 +302,9 @@ def main():
             every = [torch.empty_like(mine) for _ in range(world)]
             tdist.all_gather(every, mine)
             consistent = all(bool((e == mine).all().item()) for e in every)
+            if not consistent:
+                raise RuntimeError(f"{workload}: the replicated item state differs between ranks -- the "
+                                   "item half-sweep and its collective are not ordered; the rate would be meaningless")
         total_bytes, dom_bytes = algorithmic_bytes(workload, U, I, N, K, elem)
         dom_ms, dom_n = prof[dominant]
         achieved = (dom_bytes / 2) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0  # two launches per epoch

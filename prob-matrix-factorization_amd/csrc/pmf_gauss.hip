@@ -307,6 +307,8 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
 __device__ __forceinline__ float pair_pad_diag(float inv_sigma2, float inv_eta2) { return (1.f - inv_eta2) / inv_sigma2; }
 
 // Precondition: img / wbuf are complete and the block has synchronised.
+// FULL: K == 128, every register index is its row (static LDS offsets in the epilogue).
+template <bool FULL>
 __device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, float *gbuf, const float *wbuf, int K,
                                                 int kp, int kpad, float inv_sigma2, float inv_eta2, float *vout,
                                                 float *mout, int wave, int lane) {
@@ -324,8 +326,10 @@ __device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, f
         B[i] = v * g * gbuf[i];
         if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from piling up in VGPRs
     }
+    // Only the K real pivots are swept: the padding block is the identity and stays one.  After
+    // K steps register i holds row (i + K) mod 128 (each step rotates the rows by one register).
 #pragma unroll 1
-    for (int k = 0; k < KR; ++k) {
+    for (int k = 0; k < (FULL ? KR : K); ++k) {
         const float v = B[0];
         float *xb = xbuf + (k & 1) * 256;
         xb[j] = v;
@@ -353,20 +357,23 @@ __device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, f
     // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
     // (the bound of the packed output as a VECTOR value: a scalar `i < K` would make the
     //  compiler keep 128 masks in SGPRs and spill them)
-    int kpv = kp;
+    int kpv = kp, kv = K;
     asm volatile("" : "+v"(kpv));
+    asm volatile("" : "+v"(kv));
     float mj = 0.f;
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
-        const float vij = -B[i] * g * gbuf[i];
-        mj = fmaf(vij, wbuf[i], mj);
-        const int at = i * (i + 1) / 2 + j;
-        if (j <= i && at < kpv) vout[at] = vij;
+        const int r = FULL ? i : ((i + kv) & (KR - 1));   // the row register i holds
+        const float vij = -B[i] * g * gbuf[r];
+        mj = fmaf(vij, wbuf[r], mj);
+        const int at = r * (r + 1) / 2 + j;
+        if (j <= r && at < kpv) vout[at] = vij;
         if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
     }
     if (j < kpad) mout[j] = (j < K) ? mj * inv_sigma2 : 0.f;
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<float> p) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *img = reinterpret_cast<float *>(smem_raw);
@@ -393,8 +400,8 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
     }
     wbuf[j] = j < K ? p.src_w[(int64_t)row * p.src_w_stride + j] : 0.f;
     __syncthreads();
-    pair_solve_body(img, xbuf, gbuf, wbuf, K, p.kp, p.kpad, p.inv_sigma2, p.inv_eta2,
-                    p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
+    pair_solve_body<FULL>(img, xbuf, gbuf, wbuf, K, p.kp, p.kpad, p.inv_sigma2, p.inv_eta2,
+                          p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -405,10 +412,11 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
 // (wave 0: (0,0) (1,0) (1,1) (2,0) (2,1); wave 1: (2,2) (3,0) (3,1) (3,2) (3,3)).
 // Both waves fold their blocks into the shared LDS image; a complete row is then
 // solved in place by the same two waves (pair_solve_body).
-template <bool FUSE>
+// NT = chunk columns per wave (host picks the smallest that covers ceil(chunks / 2) / 64):
+// 17 for K = 128 (1032 chunks per wave), 13 for K <= 112, 9 for K <= 92.
+template <int NT, bool FUSE, bool FULL>
 __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams<float> p, float inv_sigma2, float inv_eta2,
                                                                      float *cov_self, float *factor_self) {
-    constexpr int NT = 17;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *img = reinterpret_cast<float *>(smem_raw);
     float *xbuf = img + PAIR_IMG, *gbuf = xbuf + 512, *wbuf = gbuf + 128;
@@ -418,7 +426,6 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
     const int K = p.K, kpad = p.kpad, stride = p.cov_stride, chunks = p.cov_stride / PMF_VEC;
     const int half = (chunks + 1) / 2;
     const int q_begin = wave ? half : 0, q_end = wave ? chunks : half;
-    const int nt = (q_end - q_begin + 63) / 64;  // uniform, <= NT
     const int32_t *col = p.other + t.start;
     const float *val = p.val + t.start;
     const float b_self = p.bias_self ? p.bias_self[t.row] : 0.f;
@@ -452,12 +459,15 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
         // one rating's chunks in flight at a time (68 VGPRs): with the MFMA blocks the kernel then
         // fits 256 registers, i.e. two blocks' worth of waves per SIMD, so one block can solve
         // while the other streams
+        // every column is loaded, clamped to the wave's last chunk: no uniform branches around the
+        // loads, and the clamped lanes (same cache line again) are never stored.  The lane base is
+        // made opaque each trip so that the 17 clamped offsets are recomputed (two VALU ops per
+        // load) instead of being kept live -- and spilled -- across the loop
+        int qb = q_begin + lane;
+        asm volatile("" : "+v"(qb));
         float4 a[NT];
 #pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s < nt) a[s] = v0[min(q_begin + lane + 64 * s, q_end - 1)];  // clamped lanes are never stored
-        }
+        for (int s = 0; s < NT; ++s) a[s] = v0[min(qb + 64 * s, q_end - 1)];
         wA = fmaf(wave ? m[2] : m[0], res, wA);
         wB = fmaf(wave ? m[3] : m[1], res, wB);
         // operand pairs of this wave's five blocks (wave is uniform: scalar selects)
@@ -481,10 +491,7 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
         __builtin_amdgcn_sched_barrier(0);
         if (two) {
 #pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s < nt) a[s] = v1[min(q_begin + lane + 64 * s, q_end - 1)];
-            }
+            for (int s = 0; s < NT; ++s) a[s] = v1[min(qb + 64 * s, q_end - 1)];
 #pragma unroll
             for (int s = 0; s < NT; ++s) {
                 acc[s].x += a[s].x;
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
             const int q = q_begin + lane + 64 * s;
-            if (s < nt && q < q_end) {
+            if (q < q_end) {
                 float4 mm = reinterpret_cast<float4 *>(img)[q];
                 mm.x += acc[s].x;
                 mm.y += acc[s].y;
@@ -545,8 +552,8 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
             }
         }
         __syncthreads();
-        pair_solve_body(img, xbuf, gbuf, wbuf, K, p.kp, kpad, inv_sigma2, inv_eta2,
-                        cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
+        pair_solve_body<FULL>(img, xbuf, gbuf, wbuf, K, p.kp, kpad, inv_sigma2, inv_eta2,
+                              cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
         return;
     }
     float *out_s, *out_w;
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
 #pragma unroll
     for (int s = 0; s < NT; ++s) {
         const int q = q_begin + lane + 64 * s;
-        if (s < nt && q < q_end) {
+        if (q < q_end) {
             const float4 mm = reinterpret_cast<const float4 *>(img)[q];
             float4 o = acc[s];
             o.x += mm.x;
@@ -998,6 +1005,18 @@ static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 gr
     }
 }
 
+template <int NT>
+static void launch_accum_mfma128(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, size_t smem, bool fuse, float is2,
+                                 float ie2, float *cov, float *fac) {
+    if (fuse && NT == 17 && ctx->K == 128)
+        hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, NT == 17>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+    else if (fuse)
+        hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+    else
+        hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, false, false>), grid, dim3(128), smem, ctx->stream, p, 0.f, 0.f,
+                           (float *)nullptr, (float *)nullptr);
+}
+
 // *fused is set when the kernel also solved every single-task row (K = 64 fp32,
 // not in stats mode); the caller then only solves the split rows.
 template <typename T>
@@ -1061,11 +1080,10 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
                 } else {  // 64 < K <= 128: one 128-thread block (two wavefronts) per task
                     const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
                     dim3 g2((unsigned)tl.n_tasks);
-                    if (fuse)
-                        hipLaunchKernelGGL(gauss_accum_mfma128_kernel<true>, g2, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
-                    else
-                        hipLaunchKernelGGL(gauss_accum_mfma128_kernel<false>, g2, dim3(128), smem, ctx->stream, p, 0.f, 0.f,
-                                           (float *)nullptr, (float *)nullptr);
+                    const int chunks = ctx->cov_stride / PMF_VEC, nt = ((chunks + 1) / 2 + 63) / 64;
+                    if (nt <= 9) launch_accum_mfma128<9>(ctx, p, g2, smem, fuse, is2, ie2, cov, fac);
+                    else if (nt <= 13) launch_accum_mfma128<13>(ctx, p, g2, smem, fuse, is2, ie2, cov, fac);
+                    else launch_accum_mfma128<17>(ctx, p, g2, smem, fuse, is2, ie2, cov, fac);
                 }
             }
         }
@@ -1132,8 +1150,12 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (ctx->K <= 64) launch_solve_reg<T, 64>(ctx, sp);
     else if (std::is_same<T, float>::value && !getenv("PMF_GAUSS_LDS_SOLVE")) {
         if constexpr (std::is_same<T, float>::value)
-            hipLaunchKernelGGL(gauss_solve_pair_kernel, dim3((unsigned)sp.n), dim3(128),
-                               (size_t)PAIR_LDS_FLOATS * sizeof(float), ctx->stream, sp);
+            if (ctx->K == 128)
+                hipLaunchKernelGGL(gauss_solve_pair_kernel<true>, dim3((unsigned)sp.n), dim3(128),
+                                   (size_t)PAIR_LDS_FLOATS * sizeof(float), ctx->stream, sp);
+            else
+                hipLaunchKernelGGL(gauss_solve_pair_kernel<false>, dim3((unsigned)sp.n), dim3(128),
+                                   (size_t)PAIR_LDS_FLOATS * sizeof(float), ctx->stream, sp);
     } else {
         const int K = ctx->K;
         size_t smem = ((size_t)K * (K + 1) + 3 * K) * sizeof(T);

@@ -126,7 +126,7 @@ def test_hot_kernels_do_not_spill_and_use_the_intended_instructions(device_asm):
         for k, f in meta.items():
             assert f["wavefront_size"] == "64", k
             if "solve_pair" in k or "mfma128" in k:   # K in (64,128]: a few spilled dwords buy 2 waves per SIMD
-                assert int(f["private_segment_fixed_size"]) <= 64, (k, f)
+                assert int(f["private_segment_fixed_size"]) <= 128, (k, f)   # spills sit outside the streaming and sweep loops
                 continue
             assert int(f["vgpr_spill_count"]) == 0, (k, f)
             # (SGPR spills only park scalars in VGPR lanes (no memory traffic; in the fused

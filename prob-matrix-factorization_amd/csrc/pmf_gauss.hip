@@ -440,22 +440,42 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
     for (int s = 0; s < NT; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     float wA = 0.f, wB = 0.f;  // rhs segments 2*wave and 2*wave + 1
 
-    // (fetching the next pair's row ids one trip ahead: 890.3 -> 886.7 ms per C4-shard epoch, i.e.
-    //  nothing; what is left at K = 128 is the row solve -- 320 ms of LDS-return-bound work per epoch
-    //  when run alone, of which ~135 ms are not hidden behind the 754 ms stream)
+    // The task's row ids and ratings are fetched 64 at a time (one coalesced load each) and handed
+    // out with v_readlane: the ids are SGPRs (scalar address arithmetic, SGPR-base loads) and no
+    // trip waits for an index.  Every load of a trip is unconditional (clamped index, value
+    // selected afterwards), so the m / rating / bias loads and the 17 covariance chunks leave
+    // back to back and the trip pays ONE memory latency per rating.  (The first version loaded
+    // the ids per trip and predicated the small loads with branches: index -> second index ->
+    // m/rating/bias -> chunks of rating 0 -> chunks of rating 1 were five dependent latencies
+    // per pair.)
+    const bool has_bias = p.bias_other != nullptr;
+    const float *bias_ptr = has_bias ? p.bias_other : p.factor_other;   // always readable
+    const int bias_mul = has_bias ? 1 : 0;
+    int idx_b = 0;
+    float val_b = 0.f;
     for (int j = 0; j < t.len; j += 2) {
+        if ((j & 63) == 0) {
+            const int jj = min(j + lane, t.len - 1);
+            idx_b = col[jj];
+            val_b = val[jj];
+        }
         const bool two = j + 1 < t.len;
-        const int o0 = col[j], o1 = two ? col[j + 1] : o0;
+        const int l0 = j & 63;   // even: l0 + 1 is in the same batch
+        const int o0 = __builtin_amdgcn_readlane(idx_b, l0);
+        const int o1 = two ? __builtin_amdgcn_readlane(idx_b, l0 + 1) : o0;
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val_b), l0));
+        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val_b), two ? l0 + 1 : l0));
         const int oh = h ? o1 : o0;
         const bool live = (h == 0) || two;
         const float *mrow = p.factor_other + (int64_t)oh * kpad;
         float m[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) m[b] = (live && 32 * b + c < K) ? mrow[32 * b + c] : 0.f;
-        const float xh = live ? val[j + h] : 0.f;
-        const float res = live ? xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f) : 0.f;
+        for (int b = 0; b < 4; ++b) m[b] = mrow[min(32 * b + c, kpad - 1)];
+        const float bo = bias_ptr[(int64_t)oh * bias_mul];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m[b] = (live && 32 * b + c < K) ? m[b] : 0.f;
+        const float res = live ? (h ? x1 : x0) - b_self - (has_bias ? bo : 0.f) : 0.f;
         const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * stride);
-        const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * stride);
         // one rating's chunks in flight at a time (68 VGPRs): with the MFMA blocks the kernel then
         // fits 256 registers, i.e. two blocks' worth of waves per SIMD, so one block can solve
         // while the other streams
@@ -467,7 +487,9 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
         asm volatile("" : "+v"(qb));
         float4 a[NT];
 #pragma unroll
-        for (int s = 0; s < NT; ++s) a[s] = v0[min(qb + 64 * s, q_end - 1)];
+        for (int s = 0; s < NT; ++s)   // uniform base + 32-bit unsigned byte offset: the SGPR-base load form
+            a[s] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(v0) +
+                                                     (unsigned)min(qb + 64 * s, q_end - 1) * 16u);
         wA = fmaf(wave ? m[2] : m[0], res, wA);
         wB = fmaf(wave ? m[3] : m[1], res, wB);
         // operand pairs of this wave's five blocks (wave is uniform: scalar selects)
@@ -490,8 +512,12 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
         }
         __builtin_amdgcn_sched_barrier(0);
         if (two) {
+            // (the id is read again here so that the base stays a scalar inside this block)
+            const float *v1 = p.cov_other + (int64_t)__builtin_amdgcn_readlane(idx_b, l0 + 1) * stride;
 #pragma unroll
-            for (int s = 0; s < NT; ++s) a[s] = v1[min(qb + 64 * s, q_end - 1)];
+            for (int s = 0; s < NT; ++s)
+                a[s] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(v1) +
+                                                         (unsigned)min(qb + 64 * s, q_end - 1) * 16u);
 #pragma unroll
             for (int s = 0; s < NT; ++s) {
                 acc[s].x += a[s].x;

@@ -655,22 +655,34 @@ __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel
     float wlo = 0.f, whi = 0.f;
 
     // one loop trip = PU pairs of ratings; FULL trips carry no validity tests
+    // The task's row ids and ratings come 64 at a time (one coalesced load each per 64 ratings) and
+    // are handed out with v_readlane: ids in SGPRs without a dependent scalar load per pair (the
+    // PU = 8 trip of K <= 16 used to wait for eight of them in turn).
+    int idx_b = 0;
+    float val_b = 0.f;
     auto trip = [&](int j, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         float4 a[PU][NT], b[PU][NT];
         float mlo[PU], mhi[PU], res[PU];
+        if ((j & 63) == 0) {   // a trip never straddles a batch: 2 PU divides 64
+            const int jj = min(j + lane, t.len - 1);
+            idx_b = col[jj];
+            val_b = val[jj];
+        }
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
-            const int j0 = j + 2 * u;
+            const int j0 = j + 2 * u, l0 = j0 & 63;
             const bool has0 = FULL || j0 < t.len, has1 = FULL || j0 + 1 < t.len;
-            const int o0 = has0 ? col[j0] : 0;
-            const int o1 = has1 ? col[j0 + 1] : o0;
+            const int o0 = __builtin_amdgcn_readlane(idx_b, l0);                 // lanes past the task hold
+            const int o1 = __builtin_amdgcn_readlane(idx_b, l0 + 1);             // its last (valid) id
+            const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val_b), l0));
+            const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val_b), l0 + 1));
             const int oh = h ? o1 : o0;
             const bool live = h ? has1 : has0;
             const float *mrow = p.factor_other + (int64_t)oh * kpad;
             mlo[u] = (live && lo_ok) ? mrow[c] : 0.f;
             mhi[u] = (live && hi_ok) ? mrow[32 + c] : 0.f;
-            const float xh = live ? val[j0 + h] : 0.f;
+            const float xh = h ? x1 : x0;
             res[u] = live ? xh - b_self - (p.bias_other ? p.bias_other[oh] : 0.f) : 0.f;
             const float4 *v0 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o0 * stride);
             const float4 *v1 = reinterpret_cast<const float4 *>(p.cov_other + (int64_t)o1 * stride);

@@ -626,8 +626,9 @@ __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel
     constexpr int NB = KB == 64 ? 3 : 1;
     // (the scheduler interleaves the trip's waits and adds with its loads -- about ten of the 18 are in
     //  flight at a time; forcing all 18 out before the first use: item sweep 68.4 -> 66.8 ms, user sweep
-    //  56.6 -> 60.4 ms, worse overall; issuing pair t+1 before consuming pair t needs 2 x 75 load registers
-    //  and spills at NT >= 8)
+    //  56.6 -> 60.4 ms, worse overall -- and selecting that form for the item sweep only changed the
+    //  epoch by less than the box-to-box noise (128.2 / 128.9 against 128.1 / 128.3 ms);
+    //  issuing pair t+1 before consuming pair t needs 2 x 75 load registers and spills at NT >= 8)
     // (measured at K = 64 / NT = 9: two pairs in flight 1-2 % slower; one rating at a time at 3 waves
     //  per SIMD 2.5 % slower than one pair at 2 waves per SIMD; non-temporal loads of the item side's
     //  streamed-once covariance rows: no difference)

@@ -308,6 +308,8 @@ __device__ __forceinline__ float pair_pad_diag(float inv_sigma2, float inv_eta2)
 
 // Precondition: img / wbuf are complete and the block has synchronised.
 // FULL: K == 128, every register index is its row (static LDS offsets in the epilogue).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <bool FULL>
 __device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, float *gbuf, const float *wbuf, int K,
                                                 int kp, int kpad, float inv_sigma2, float inv_eta2, float *vout,
@@ -317,54 +319,87 @@ __device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, f
     const float g = 1.f / sqrtf(img[j * (j + 3) / 2] * inv_sigma2 + inv_eta2);
     gbuf[j] = g;
     __syncthreads();
-    float B[KR];
+    // Rows are kept in PAIRS of registers (B2[i] = rows 2i, 2i+1 of this lane's column) so that the
+    // rank-1 update runs as v_pk_fma_f32 -- two rows per instruction, the pair of row scalars coming
+    // from one aligned LDS read.
+    f32x2 B2[KR / 2];
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         float v = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
         if (i == j) v += inv_eta2;
-        B[i] = v * g * gbuf[i];
+        B2[i >> 1][i & 1] = v * g * gbuf[i];
         if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from piling up in VGPRs
     }
-    // Only the K real pivots are swept: the padding block is the identity and stays one.  After
-    // K steps register i holds row (i + K) mod 128 (each step rotates the rows by one register).
-#pragma unroll 1
-    for (int k = 0; k < (FULL ? KR : K); ++k) {
-        const float v = B[0];
-        float *xb = xbuf + (k & 1) * 256;
-        xb[j] = v;
-        xb[128 + j] = v;
+    // Two pivots per trip.  At the top of a trip register r holds row (k + r) mod 128, k even.
+    //   step A  pivot row k   = register 0: rows updated in place;
+    //   step B  pivot row k+1 = register 1: rows updated and moved down two registers
+    //           (row k -> register 126, the pivot row -> register 127),
+    // so both steps work on aligned register pairs.  The lane that owns column c publishes its pivot
+    // element at xb[(c - k) mod 128]: xb[r] is then the pivot row's element in column k + r, which by
+    // symmetry is the scalar s_r of register r, at a fixed, 16-byte aligned address.
+    // Only the K real pivots are swept (the padding block is the identity and stays one).
+    const int npair = (FULL ? KR : K) >> 1;
+    const f32x2 *xa2 = reinterpret_cast<const f32x2 *>(xbuf), *xb2 = reinterpret_cast<const f32x2 *>(xbuf + 128);
+    auto step_a = [&](int k) {
+        const float v = B2[0][0];
+        xbuf[(j - k) & (KR - 1)] = v;
         __syncthreads();
-        const float *sk = xb + k;  // sk[i] = element (k + i) mod 128 of the pivot row = s of register i
-        const float pinv = 1.f / sk[0];
+        const float pinv = 1.f / xbuf[0];
         const float u = v * pinv;
         const float uc = (j == k) ? (1.f - pinv) : u;
-        // batches of 16 scalars: keeps the live set small instead of letting the scheduler
-        // hoist all 127 LDS reads into registers
+        const f32x2 uc2 = {uc, uc};
 #pragma unroll
-        for (int i0 = 1; i0 < KR; i0 += 16) {
-            float sc[16];
+        for (int i0 = 0; i0 < KR / 2; i0 += 8) {   // batches keep the live set small
+            f32x2 sc[8];
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (i0 + q < KR) sc[q] = sk[i0 + q];
+            for (int q = 0; q < 8; ++q) sc[q] = xa2[i0 + q];
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (i0 + q < KR) B[i0 + q - 1] = fmaf(-sc[q], uc, B[i0 + q]);
+            for (int q = 0; q < 8; ++q) B2[i0 + q] = __builtin_elementwise_fma(-sc[q], uc2, B2[i0 + q]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        B[KR - 1] = (j == k) ? -pinv : u;
+        B2[0][0] = (j == k) ? -pinv : u;   // the pivot row itself
+    };
+#pragma unroll 1
+    for (int kk = 0; kk < npair; ++kk) {
+        const int k = 2 * kk;
+        step_a(k);
+        {
+            const float v = B2[0][1];
+            xbuf[128 + ((j - k) & (KR - 1))] = v;
+            __syncthreads();
+            const float pinv = 1.f / xbuf[128 + 1];
+            const float u = v * pinv;
+            const float uc = (j == k + 1) ? (1.f - pinv) : u;
+            const f32x2 uc2 = {uc, uc};
+            f32x2 first = __builtin_elementwise_fma(-xb2[0], uc2, B2[0]);   // row k (kept) | pivot row (replaced)
+#pragma unroll
+            for (int i0 = 1; i0 < KR / 2; i0 += 8) {
+                f32x2 sc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < KR / 2) sc[q] = xb2[i0 + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < KR / 2) B2[i0 + q - 1] = __builtin_elementwise_fma(-sc[q], uc2, B2[i0 + q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            first[1] = (j == k + 1) ? -pinv : u;
+            B2[KR / 2 - 1] = first;
+        }
     }
+    if (!FULL && (K & 1)) step_a(K - 1);   // odd K: the last pivot, rows stay where they are
     // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
     // (the bound of the packed output as a VECTOR value: a scalar `i < K` would make the
     //  compiler keep 128 masks in SGPRs and spill them)
-    int kpv = kp, kv = K;
+    int kpv = kp, kv = 2 * npair;   // register i holds row (i + 2 npair) mod 128
     asm volatile("" : "+v"(kpv));
     asm volatile("" : "+v"(kv));
     float mj = 0.f;
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
         const int r = FULL ? i : ((i + kv) & (KR - 1));   // the row register i holds
-        const float vij = -B[i] * g * gbuf[r];
+        const float vij = -B2[i >> 1][i & 1] * g * gbuf[r];
         mj = fmaf(vij, wbuf[r], mj);
         const int at = r * (r + 1) / 2 + j;
         if (j <= r && at < kpv) vout[at] = vij;

@@ -164,6 +164,13 @@ extern "C" int pmf_ctx_create(int device, int64_t n_users, int64_t n_items, int 
     ctx->rows[1] = n_items;
     ctx->K = n_factors;
     ctx->kpad = (n_factors + PMF_VEC - 1) / PMF_VEC * PMF_VEC;
+    {
+        // Factor rows are gathered at random: a row whose tail (row bytes mod 128) exceeds 64 bytes makes
+        // at least every second gather touch one 128-byte line more than a line-aligned row would
+        // (K = 20 fp32: 80-byte rows, 1.5 lines on average against 1).  Such rows are padded to the line.
+        const int line = 128 / (int)ctx->elem;
+        if ((ctx->kpad % line) * (int)ctx->elem > 64) ctx->kpad = (ctx->kpad + line - 1) / line * line;
+    }
     ctx->kp = n_factors * (n_factors + 1) / 2;
     ctx->cov_stride = (ctx->kp + PMF_VEC - 1) / PMF_VEC * PMF_VEC;
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);

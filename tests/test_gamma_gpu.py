@@ -72,7 +72,7 @@ def test_verbose_log_matches_reference(capsys):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-11), ("f32", 3e-5)])
-@pytest.mark.parametrize("K", [1, 3, 8, 20, 40, 64, 100, 128, 256])
+@pytest.mark.parametrize("K", [1, 3, 8, 20, 28, 40, 52, 64, 100, 128, 250, 256])
 def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
     """Direct C-ABI calls on a skewed problem: rows far above one chunk (split
     rows), empty rows, every lane-group width."""

@@ -124,7 +124,7 @@ def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
         assert np.max(np.abs(got[key] - st[key]) / scale) <= tol, key
 
 
-@pytest.mark.parametrize("K", [5, 16, 30, 32, 33, 40, 64, 70, 100, 128])
+@pytest.mark.parametrize("K", [5, 16, 20, 30, 32, 33, 40, 52, 64, 70, 100, 120, 128])
 def test_mfma_kernel_matches_generic_kernel(K, monkeypatch):
     """The fp32 fast paths (K <= 64: one wavefront per task; 64 < K <= 128: two) (MFMA outer products, fused solve) against the
     generic accumulate kernel + standalone solve on the same inputs."""

@@ -46,6 +46,10 @@ WORKLOADS = {
     "hpf_cavi": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
                      hp=dict(a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0),
                      label="hpf_cavi K=64, 1Mx100k synthetic, 50M ratings per GPU"),
+    # MAP / gradient mode of the Gaussian model (no reference counterpart, parity unpinned)
+    "gaussian_mf_sgd": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
+                            hp=dict(lr=0.01, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0),
+                            label="gaussian_mf MAP by gradient steps K=64, 1Mx100k synthetic, 50M ratings per GPU"),
 }
 SMALL = dict(U=100_000, I=10_000, N=5_000_000)  # --small: quick functional run
 
@@ -55,6 +59,10 @@ def algorithmic_bytes(workload, U, I, N, K, elem=4):
     Returns (total per iteration, per dominant-kernel launch summed over the two
     sides).  fp32 values, int32 indices."""
     kp = K * (K + 1) // 2
+    if workload == "gaussian_mf_sgd":
+        per_rating = elem * K + 12                      # gathered row + idx + rating + bias
+        total = N * 2 * per_rating + (U + I) * (4 * elem * K + 16)   # row read, statistics written + read, row written
+        return total, total
     if workload.startswith("gaussian_mf"):
         per_rating_factor = elem * K + elem * kp + 12   # mean row + packed cov + idx + rating + bias
         per_rating_bias = elem * K + 12
@@ -218,7 +226,8 @@ def main():
     def run(workload, hp, steps, warmup):
         """Build the device state of `workload` on the shared ratings, run warmup + timed steps
         (barrier + synchronize on both sides, max over ranks) and return the measurements."""
-        gauss = workload.startswith("gaussian_mf")
+        sgd = workload == "gaussian_mf_sgd"
+        gauss = workload.startswith("gaussian_mf") and not sgd
         ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
         # kernels, RCCL collectives and torch allocations share one non-default stream
         scope = pdist.StreamScope(ctx, device).enter()
@@ -227,7 +236,7 @@ def main():
             ctx.set_row_chunks(ITEM, n_chunks)
         rng = np.random.default_rng(42)
         t0 = time.time()
-        if gauss:
+        if gauss or sgd:
             ctx.set_ratings(u, i, r - float(r.mean()))  # centred as compare_models.py:54-65
         else:
             ctx.set_ratings(u, i, r + 1.0)              # +1 shift as compare_models.py:180-185
@@ -250,6 +259,20 @@ def main():
                 pdist.gaussian_iteration(ctx, comm, stats_item, stats_bias, hp["sigma2"], hp["eta_theta2"],
                                          hp["eta_beta2"], hp["eta_bias2"])
             dominant = "gauss_accum"
+        elif sgd:
+            init_u, init_i = 0.1 * rng.standard_normal((U, K)), 0.1 * np.random.default_rng(43).standard_normal((I, K))
+            t0 = time.time()
+            ctx.set_array(USER, ARR_FACTOR, init_u)
+            ctx.set_array(ITEM, ARR_FACTOR, init_i)
+            ctx.set_array(USER, ARR_BIAS, np.zeros(U))
+            ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
+            if comm is not None:
+                stats_item = pdist.sgd_stats(ctx, device)
+
+            def step():
+                pdist.gaussian_sgd_iteration(ctx, comm, stats_item, hp["lr"], hp["sigma2"], hp["eta_theta2"],
+                                             hp["eta_beta2"], hp["eta_bias2"])
+            dominant = "gauss_sgd"
         else:
             # hpf_cavi.py:66-89 initial state
             init_u = (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K)))
@@ -307,7 +330,7 @@ def main():
                                    "item half-sweep and its collective are not ordered; the rate would be meaningless")
         total_bytes, dom_bytes = algorithmic_bytes(workload, U, I, N, K, elem)
         dom_ms, dom_n = prof[dominant]
-        achieved = (dom_bytes / 2) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_n else 0.0  # two launches per epoch
+        achieved = dom_bytes / (dom_ms / steps * 1e-3) / 1e9 if dom_n else 0.0  # bytes per epoch / kernel time per epoch
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and not args.small and args.dtype == "f32" and not args.factors:
@@ -349,7 +372,8 @@ def main():
         return
 
     out = {
-        "metric": f"ratings/sec (epoch) Gaussian-MF K={K}" if gauss else f"ratings/sec (epoch) HPF-CAVI K={K}",
+        "metric": (f"ratings/sec (epoch) Gaussian-MF MAP/SGD K={K}" if args.workload == "gaussian_mf_sgd" else
+                   f"ratings/sec (epoch) Gaussian-MF K={K}" if gauss else f"ratings/sec (epoch) HPF-CAVI K={K}"),
         "value": main_res["value"], "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -375,7 +399,7 @@ def main():
                                     "value": also["value"], "ms_per_step": also["ms_per_step"], "steps": also["steps"],
                                     "epoch_fraction_of_hbm_roofline": also["epoch_fraction_of_hbm_roofline"],
                                     "roofline": also["roofline"]}}
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.workload != "gaussian_mf_sgd":
         out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank)
         if also is not None:
             out["also"]["hpf_cavi"]["cpu_baseline"] = cpu_baseline("hpf_cavi", K, WORKLOADS["hpf_cavi"]["hp"], local_rank)

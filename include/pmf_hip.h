@@ -82,7 +82,8 @@ extern "C" {
 #define PMF_KERNEL_PREDICT 6
 #define PMF_KERNEL_TOPK 7
 #define PMF_KERNEL_GAUSS_COMBINE 8 /* split-row partial sums -> row sums */
-#define PMF_KERNEL_COUNT 9
+#define PMF_KERNEL_GAUSS_SGD 9     /* MAP gradient half-sweep (no reference counterpart) */
+#define PMF_KERNEL_COUNT 10
 
 typedef struct pmf_ctx pmf_ctx;
 
@@ -204,6 +205,23 @@ int pmf_gauss_factor_finalize(pmf_ctx *ctx, int side, const void *stats_dev, dou
 int pmf_gauss_bias_accumulate(pmf_ctx *ctx, int side, void *stats_dev);
 int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,
                             double eta_bias2);
+
+/* ---- Gaussian MF, MAP by stochastic gradient steps -------------
+ * NO reference counterpart (the reference's Gaussian model is CAVI only): parity unpinned, the
+ * oracle is this build's own restatement (oracle/cavi_oracle.py:gauss_sgd_half_sweep).  One call
+ * walks every row of `side` through its ratings in input order with the other side fixed:
+ *   e = x - b_r - b_o - f_r . f_o;  f_r += lr (e f_o / sigma2 - f_r / (eta2 n_r));
+ *   b_r += lr (e / sigma2 - b_r / (eta_bias2 n_r))        (biases only if both BIAS arrays are set)
+ * Rows longer than 256 ratings are cut into pieces that start from the row's old value; the row
+ * moves by the rating-count-weighted mean of the pieces' displacements.  The accumulate / finalize
+ * pair exposes that sum -- [rows x width] = sum len * d_f | sum len * d_b | sum len | 0 0, width from
+ * pmf_ctx_sgd_stats_width -- so that ranks holding different ratings of an item can all-reduce it
+ * (honours pmf_ctx_select_chunk like the other accumulate / finalize calls). */
+int pmf_gauss_sgd_sweep(pmf_ctx *ctx, int side, double lr, double sigma2, double eta2, double eta_bias2);
+int pmf_ctx_sgd_stats_width(pmf_ctx *ctx, int *width);
+int pmf_gauss_sgd_accumulate(pmf_ctx *ctx, int side, void *stats_dev, double lr, double sigma2, double eta2,
+                             double eta_bias2);
+int pmf_gauss_sgd_finalize(pmf_ctx *ctx, int side, const void *stats_dev);
 
 /* ---- predict / evaluate -------------------------------------------------
  * `predict` (hpf_cavi.py:215-231, poisson_mf_cavi.py:221-241,

@@ -361,6 +361,71 @@ def gaussian_iteration(st, idx, u, i, x, sigma2, eta_theta2, eta_beta2, eta_bias
 
 
 # --------------------------------------------------------------------------
+# Gaussian MF, MAP by gradient steps  (SURVEY.md 8(f) rank 4 -- NO reference
+# counterpart: this restates the ENGINE's own definition, include/pmf_hip.h
+# `pmf_gauss_sgd_sweep`, so parity of this mode is UNPINNED)
+# --------------------------------------------------------------------------
+def sgd_pieces(n, chunk=256):
+    """Lengths of the pieces a row of n ratings is cut into (the engine's task
+    builder): one piece up to `chunk`, else q = ceil(n / chunk) nearly equal ones."""
+    if n <= chunk:
+        return [n]
+    q = -(-n // chunk)
+    base, extra = divmod(n, q)
+    return [base + (1 if c < extra else 0) for c in range(q)]
+
+
+def gauss_sgd_half_sweep(f_self, f_other, b_self, b_other, ptr, pos, other_ids, x, lr, sigma2, eta2,
+                         eta_bias2, chunk=256):
+    """Every row walks through its ratings in input order with the other side fixed:
+    e = x - b_r - b_o - f_r.f_o; f_r += lr (e f_o / sigma2 - f_r / (eta2 n_r));
+    b_r += lr (e / sigma2 - b_r / (eta_bias2 n_r)).  Pieces of a long row start from the
+    row's old value; the row moves by the length-weighted mean of their displacements.
+    Returns new (f_self, b_self); b_* may be None (model without biases)."""
+    f_new = f_self.copy()
+    b_new = None if b_self is None else b_self.copy()
+    for r in range(ptr.size - 1):
+        lo, hi = int(ptr[r]), int(ptr[r + 1])
+        n = hi - lo
+        if n == 0:
+            continue
+        d_f, d_b, at = np.zeros(f_self.shape[1]), 0.0, lo
+        for length in sgd_pieces(n, chunk):
+            th = f_self[r].copy()
+            b = 0.0 if b_self is None else float(b_self[r])
+            for p in pos[at:at + length]:
+                o = other_ids[p]
+                be = f_other[o]
+                e = x[p] - b - (0.0 if b_other is None else b_other[o]) - float(th @ be)
+                th = th + lr * (e * be / sigma2 - th / (eta2 * n))
+                if b_self is not None:
+                    b = b + lr * (e / sigma2 - b / (eta_bias2 * n))
+            d_f += length * (th - f_self[r])
+            d_b += length * (b - (0.0 if b_self is None else float(b_self[r])))
+            at += length
+        f_new[r] = f_self[r] + d_f / n
+        if b_self is not None:
+            b_new[r] = b_self[r] + d_b / n
+    return f_new, b_new
+
+
+def gauss_sgd_epoch(st, idx, u, i, x, lr, sigma2, eta_theta2, eta_beta2, eta_bias2=None):
+    """Users with the items fixed, then items with the new users (the CAVI order)."""
+    (uptr, upos), (iptr, ipos) = idx
+    bias = eta_bias2 is not None
+    bu, bi = (st["m_user_bias"], st["m_item_bias"]) if bias else (None, None)
+    st["m_theta"], new_bu = gauss_sgd_half_sweep(st["m_theta"], st["m_beta"], bu, bi, uptr, upos, i, x, lr, sigma2,
+                                                 eta_theta2, eta_bias2 if bias else 1.0)
+    if bias:
+        st["m_user_bias"] = bu = new_bu
+    st["m_beta"], new_bi = gauss_sgd_half_sweep(st["m_beta"], st["m_theta"], bi, bu, iptr, ipos, u, x, lr, sigma2,
+                                                eta_beta2, eta_bias2 if bias else 1.0)
+    if bias:
+        st["m_item_bias"] = new_bi
+    return st
+
+
+# --------------------------------------------------------------------------
 # predict / metrics  (rows a10 / a11)
 # --------------------------------------------------------------------------
 def predict_dot(A, B, user_ids, item_ids, bias_u=None, bias_i=None, offset=0.0):

@@ -21,7 +21,7 @@ USER, ITEM = 0, 1
  ARR_SCALE_RATE) = range(10)
 PREDICT_BIAS, PREDICT_SCALE = 1, 2
 KERNEL_NAMES = ("gamma_sweep", "gamma_final", "gauss_accum", "gauss_solve", "gauss_bias",
-                "eval", "predict", "topk", "gauss_combine")
+                "eval", "predict", "topk", "gauss_combine", "gauss_sgd")
 MAX_LABELS = 32
 
 
@@ -47,6 +47,10 @@ SIGNATURES = {
     "pmf_ctx_destroy": (C.c_int, [_p]),
     "pmf_ctx_set_stream": (C.c_int, [_p, _p]),
     "pmf_ctx_sync": (C.c_int, [_p]),
+    "pmf_gauss_sgd_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "pmf_ctx_sgd_stats_width": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "pmf_gauss_sgd_accumulate": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "pmf_gauss_sgd_finalize": (C.c_int, [_p, C.c_int, _p]),
     "pmf_ctx_set_row_chunks": (C.c_int, [_p, C.c_int, C.c_int]),
     "pmf_ctx_chunk_rows": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmf_ctx_select_chunk": (C.c_int, [_p, C.c_int, C.c_int]),

@@ -139,6 +139,18 @@ def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2,
         engine.gauss_bias_finalize(ITEM, stats_bias.ptr, sigma2, eta_bias2)
 
 
+def gaussian_sgd_iteration(engine, comm, stats_item, lr, sigma2, eta_theta2, eta_beta2, eta_bias2):
+    """One epoch of the MAP / gradient mode (no reference counterpart): users, then items; on
+    several ranks the items' rating-count-weighted displacement sums are all-reduced."""
+    engine.gauss_sgd_sweep(USER, lr, sigma2, eta_theta2, eta_bias2)
+    if comm is None or comm.world == 1:
+        engine.gauss_sgd_sweep(ITEM, lr, sigma2, eta_beta2, eta_bias2)
+        return
+    _item_half_sweep(engine, comm, stats_item, engine.sgd_stats_width,
+                     lambda: engine.gauss_sgd_accumulate(ITEM, stats_item.ptr, lr, sigma2, eta_beta2, eta_bias2),
+                     lambda: engine.gauss_sgd_finalize(ITEM, stats_item.ptr))
+
+
 class StreamScope:
     """Puts one engine context and torch (its allocator, its collectives) on the SAME
     non-default HIP stream, so that kernels, all-reduces and copies are ordered without
@@ -207,6 +219,10 @@ def item_message_bytes(ctx, gaussian):
 
 def gamma_stats(ctx, device):
     return DeviceStats(ctx.n_items * 2 * ctx.kpad, ctx.np_dtype, device)
+
+
+def sgd_stats(ctx, device):
+    return DeviceStats(ctx.n_items * ctx.sgd_stats_width, ctx.np_dtype, device)
 
 
 def gauss_stats(ctx, device):

@@ -158,6 +158,24 @@ class Context:
         check(self._lib.pmf_gauss_bias_finalize(self._h, side, C.c_void_p(stats_ptr), float(sigma2),
                                                 float(eta_bias2)), "pmf_gauss_bias_finalize")
 
+    # ---- Gaussian MAP by gradient steps (no reference counterpart) -------
+    def gauss_sgd_sweep(self, side, lr, sigma2, eta2, eta_bias2=1.0):
+        check(self._lib.pmf_gauss_sgd_sweep(self._h, side, float(lr), float(sigma2), float(eta2), float(eta_bias2)),
+              "pmf_gauss_sgd_sweep")
+
+    @property
+    def sgd_stats_width(self):
+        w = C.c_int(0)
+        check(self._lib.pmf_ctx_sgd_stats_width(self._h, C.byref(w)), "pmf_ctx_sgd_stats_width")
+        return w.value
+
+    def gauss_sgd_accumulate(self, side, stats_ptr, lr, sigma2, eta2, eta_bias2=1.0):
+        check(self._lib.pmf_gauss_sgd_accumulate(self._h, side, C.c_void_p(stats_ptr), float(lr), float(sigma2),
+                                                 float(eta2), float(eta_bias2)), "pmf_gauss_sgd_accumulate")
+
+    def gauss_sgd_finalize(self, side, stats_ptr):
+        check(self._lib.pmf_gauss_sgd_finalize(self._h, side, C.c_void_p(stats_ptr)), "pmf_gauss_sgd_finalize")
+
     # ---- predict / evaluate --------------------------------------------
     @staticmethod
     def _clip_ids(ids):

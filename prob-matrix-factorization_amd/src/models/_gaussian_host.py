@@ -68,6 +68,25 @@ class GaussianHost(DeviceModel):
         if self._comm is not None:
             self._finish_sharded(arrays)
 
+    # ---- what one iteration is (the MAP / gradient subclass overrides these two) ----
+    _iteration_label = "CAVI iteration"
+
+    def _prepare(self, ctx):
+        ctx.set_cov_identity(USER, 1.0)
+        ctx.set_cov_identity(ITEM, 1.0)
+        self._stats = (None, None)
+        if self._comm is not None:
+            self._stats = pdist.gauss_stats(ctx, self._device_obj())
+
+    @staticmethod
+    def _should_stop(improvement, tol):
+        return improvement >= 0 and improvement < tol   # gaussian_mf_cavi_bias.py:279
+
+    def _iterate(self, ctx):
+        cfg = self.config
+        pdist.gaussian_iteration(ctx, self._comm, self._stats[0], self._stats[1], cfg.sigma2, cfg.eta_theta2,
+                                 cfg.eta_beta2, cfg.eta_bias2 if self._uses_bias else None)
+
     def fit(self, train_df, val_df=None, global_mean=0.0):
         cfg = self.config
         self.global_mean = global_mean
@@ -77,21 +96,16 @@ class GaussianHost(DeviceModel):
         ctx = self._open_context(u, i, x)
         ctx.set_array(USER, ARR_FACTOR, self._mine(self.m_theta))
         ctx.set_array(ITEM, ARR_FACTOR, self.m_beta)
-        ctx.set_cov_identity(USER, 1.0)
-        ctx.set_cov_identity(ITEM, 1.0)
         if self._uses_bias:
             ctx.set_array(USER, ARR_BIAS, self._mine(self.m_user_bias))
             ctx.set_array(ITEM, ARR_BIAS, self.m_item_bias)
-        stats_item = stats_bias = None
-        if self._comm is not None:
-            stats_item, stats_bias = pdist.gauss_stats(ctx, self._device_obj())
+        self._prepare(ctx)
         monitor = self._monitor_setup(val_df, offset=global_mean, drop_unseen=True)
         previous = None
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
-                print(f"\nCAVI iteration {it}/{cfg.max_iter}")
-            pdist.gaussian_iteration(ctx, self._comm, stats_item, stats_bias, cfg.sigma2, cfg.eta_theta2,
-                                     cfg.eta_beta2, cfg.eta_bias2 if self._uses_bias else None)
+                print(f"\n{self._iteration_label} {it}/{cfg.max_iter}")
+            self._iterate(ctx)
             self._tick(it)
             if monitor is None:
                 continue
@@ -106,7 +120,7 @@ class GaussianHost(DeviceModel):
                 improvement = previous - val_rmse
                 if cfg.verbose:
                     print(f"Improvement: {improvement:.6f}")
-                if improvement >= 0 and improvement < cfg.tol:  # gaussian_mf_cavi_bias.py:279
+                if self._should_stop(improvement, cfg.tol):
                     if cfg.verbose:
                         print("Early stopping: small improvement on validation.")
                     self.history_["stopped_early"] = True

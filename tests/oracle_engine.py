@@ -172,3 +172,40 @@ class OracleEngine:
         rows = self.n_users if side == USER else self.n_items
         s = np.asarray(stats).reshape(rows, 2)
         self._bias_apply(side, s[:, 0], s[:, 1], sigma2, eta_bias2)
+
+    # --- Gaussian MAP / gradient mode (no reference counterpart) -------------
+    @property
+    def sgd_stats_width(self):
+        return self.K + 4
+
+    def _sgd_new(self, side, lr, sigma2, eta2, eta_bias2):
+        ptr, pos, oid = self._sides(side)
+        me, ot = ("theta", "beta") if side == USER else ("beta", "theta")
+        bs, bo = ("m_user_bias", "m_item_bias") if side == USER else ("m_item_bias", "m_user_bias")
+        f_new, b_new = orc.gauss_sgd_half_sweep(self.st[f"m_{me}"], self.st[f"m_{ot}"], self.st[bs], self.st[bo],
+                                                ptr, pos, oid, self.x, lr, sigma2, eta2, eta_bias2)
+        return f"m_{me}", bs, f_new, b_new, np.diff(ptr).astype(np.float64)
+
+    def gauss_sgd_sweep(self, side, lr, sigma2, eta2, eta_bias2):
+        kf, kb, f_new, b_new, _ = self._sgd_new(side, lr, sigma2, eta2, eta_bias2)
+        self.st[kf], self.st[kb] = f_new, b_new
+
+    def gauss_sgd_accumulate(self, side, stats, lr, sigma2, eta2, eta_bias2):
+        kf, kb, f_new, b_new, n = self._sgd_new(side, lr, sigma2, eta2, eta_bias2)
+        block = np.zeros((n.size, self.K + 4))
+        block[:, :self.K] = n[:, None] * (f_new - self.st[kf])
+        block[:, self.K] = n * (b_new - self.st[kb])
+        block[:, self.K + 1] = n
+        self._put(side, stats, block)
+
+    def gauss_sgd_finalize(self, side, stats):
+        kf, kb = ("m_theta", "m_user_bias") if side == USER else ("m_beta", "m_item_bias")
+        s = np.asarray(stats).reshape(self._rows(side), self.K + 4)
+        lo, hi = self._window(side)
+        live = s[:, self.K + 1] > 0
+        live[:lo] = False
+        live[hi:] = False
+        f, b = self.st[kf].copy(), self.st[kb].copy()
+        f[live] += s[live, :self.K] / s[live, self.K + 1][:, None]
+        b[live] += s[live, self.K] / s[live, self.K + 1]
+        self.st[kf], self.st[kb] = f, b

@@ -49,6 +49,15 @@ def _worker(rank, world, port, kind, out_dir, chunks=1):
             pdist.gamma_iteration(eng, comm, stats, up, ip)
         res = {"E_theta": eng.st["E_theta"], "E_beta": eng.st["E_beta"], "E_xi": eng.st["E_xi"],
                "E_eta": eng.st["E_eta"]}
+    elif kind == "sgd":
+        eng.x = lx - 4.0
+        st = orc.init_gaussian(U, I, K, seed=1, bias=True)
+        eng.st = {"m_theta": st["m_theta"][lo:hi], "m_beta": st["m_beta"], "m_user_bias": st["m_user_bias"][lo:hi],
+                  "m_item_bias": st["m_item_bias"]}
+        s_item = CpuStats(I * eng.sgd_stats_width)
+        for _ in range(3):
+            pdist.gaussian_sgd_iteration(eng, comm, s_item, 0.02, 0.5, 1.0, 1.0, 1.5)
+        res = {k: eng.st[k] for k in ("m_theta", "m_beta", "m_user_bias", "m_item_bias")}
     else:
         xc = lx - 4.0
         eng.x = xc
@@ -123,3 +132,49 @@ def test_shard_bounds_never_leave_a_rank_without_users():
         assert b[0] == 0 and b[-1] == 10 and np.all(np.diff(b) >= 1)
     with pytest.raises(ValueError):
         pdist.shard_bounds(u, 10, 11)
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_two_rank_sgd_epochs_follow_the_partitioned_definition(chunks, tmp_path):
+    """Gradient mode over two ranks (gloo): users local, the items' rating-count-weighted
+    displacement sums all-reduced -- against the same definition evaluated in one process
+    (a half-sweep per shard from the old item values, displacements averaged by count)."""
+    import torch.multiprocessing as mp
+    from oracle import cavi_oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "prob-matrix-factorization_amd"))
+    from pmf_hip import dist as pdist
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), "sgd", str(tmp_path), chunks), nprocs=world, join=True)
+    u, i, x = _problem()
+    x = x - 4.0
+    U, I, K = 400, 60, 6
+    st = orc.init_gaussian(U, I, K, seed=1, bias=True)
+    bounds = pdist.shard_bounds(u, U, world)
+    shards = [pdist.take_shard(u, i, x, bounds, g) for g in range(world)]
+    for _ in range(3):
+        new_t, new_bu = st["m_theta"].copy(), st["m_user_bias"].copy()
+        for g, (lu, li, lx) in enumerate(shards):            # user side: local to the shard
+            lo, hi = int(bounds[g]), int(bounds[g + 1])
+            ptr, pos = orc.group_positions(lu, hi - lo)
+            f, b = orc.gauss_sgd_half_sweep(st["m_theta"][lo:hi], st["m_beta"], st["m_user_bias"][lo:hi],
+                                            st["m_item_bias"], ptr, pos, li, lx, 0.02, 0.5, 1.0, 1.5)
+            new_t[lo:hi], new_bu[lo:hi] = f, b
+        st["m_theta"], st["m_user_bias"] = new_t, new_bu
+        num_f, num_b, cnt = np.zeros((I, K)), np.zeros(I), np.zeros(I)
+        for g, (lu, li, lx) in enumerate(shards):            # item side: weighted mean over the shards
+            lo, hi = int(bounds[g]), int(bounds[g + 1])
+            ptr, pos = orc.group_positions(li, I)
+            f, b = orc.gauss_sgd_half_sweep(st["m_beta"], st["m_theta"][lo:hi], st["m_item_bias"],
+                                            st["m_user_bias"][lo:hi], ptr, pos, lu, lx, 0.02, 0.5, 1.0, 1.5)
+            n = np.diff(ptr).astype(float)
+            num_f += n[:, None] * (f - st["m_beta"]); num_b += n * (b - st["m_item_bias"]); cnt += n
+        live = cnt > 0
+        st["m_beta"][live] += num_f[live] / cnt[live, None]
+        st["m_item_bias"][live] += num_b[live] / cnt[live]
+    parts = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    got_t = np.concatenate([p["m_theta"] for p in parts])
+    assert np.max(np.abs(got_t - st["m_theta"])) <= 1e-12
+    assert np.max(np.abs(np.concatenate([p["m_user_bias"] for p in parts]) - st["m_user_bias"])) <= 1e-12
+    for p in parts:
+        assert np.max(np.abs(p["m_beta"] - st["m_beta"])) <= 1e-12
+        assert np.max(np.abs(p["m_item_bias"] - st["m_item_bias"])) <= 1e-12

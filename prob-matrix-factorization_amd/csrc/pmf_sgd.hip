@@ -121,16 +121,26 @@ __global__ __launch_bounds__(256) void gauss_sgd_kernel(SgdParams<T> p) {
     }
 }
 
-// split rows: slots added in slot order (deterministic)
+// split rows: the slots of a row are summed by G slot lanes per element (slot q goes to lane
+// q mod G), the G partial sums are then added in lane order -- a fixed order, so deterministic.
+// (A popular item has thousands of slots: one thread per element walking all of them took 1.5 ms.)
 template <typename T>
-__global__ void gauss_sgd_combine_kernel(SgdParams<T> p) {
+__global__ __launch_bounds__(1024) void gauss_sgd_combine_kernel(SgdParams<T> p, int lanes_k) {
+    extern __shared__ __align__(16) unsigned char sgd_smem[];
+    T *red = reinterpret_cast<T *>(sgd_smem);   // [G][lanes_k]
     const int64_t s = blockIdx.x;
-    if (s >= p.n_split) return;
     const PmfSplitRow sr = p.split[s];
-    for (int k = threadIdx.x; k < p.width; k += blockDim.x) {
-        T sum = (T)0;
-        for (int q = 0; q < sr.n_slots; ++q) sum += p.partial[(int64_t)(sr.first_slot + q) * p.width + k];
-        p.stats[(int64_t)sr.row * p.width + k] = sum;
+    const int G = blockDim.x / lanes_k;
+    const int k = threadIdx.x % lanes_k, g = threadIdx.x / lanes_k;
+    T sum = (T)0;
+    if (k < p.width)
+        for (int q = g; q < sr.n_slots; q += G) sum += p.partial[(int64_t)(sr.first_slot + q) * p.width + k];
+    red[g * lanes_k + k] = sum;
+    __syncthreads();
+    if (g == 0 && k < p.width) {
+        T total = (T)0;
+        for (int gg = 0; gg < G; ++gg) total += red[gg * lanes_k + k];
+        p.stats[(int64_t)sr.row * p.width + k] = total;
     }
 }
 
@@ -208,8 +218,12 @@ int run_sgd(pmf_ctx *ctx, int side, int mode, void *stats, double lr, double sig
                 default: launch_sgd<T, 64>(ctx, p); break;
             }
         }
-        if (tl.n_split > 0)
-            hipLaunchKernelGGL((gauss_sgd_combine_kernel<T>), dim3((unsigned)tl.n_split), dim3(128), 0, ctx->stream, p);
+        if (tl.n_split > 0) {
+            int lanes_k = 1;
+            while (lanes_k < p.width) lanes_k <<= 1;   // width <= 260 -> at most 512
+            hipLaunchKernelGGL((gauss_sgd_combine_kernel<T>), dim3((unsigned)tl.n_split), dim3(1024),
+                               (size_t)1024 * sizeof(T), ctx->stream, p, lanes_k);
+        }
     } else {
         PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_SGD);
         const int64_t n = (tl.row1 - tl.row0) * (int64_t)(ctx->kpad + 1);

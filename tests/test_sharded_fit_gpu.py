@@ -41,6 +41,11 @@ def _build(kind, comm=None):
         from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
         return PoissonMFCAVI(PoissonMFCAVIConfig(n_factors=12, a0=0.1, b0=0.5, max_iter=6, tol=None, verbose=False),
                              dtype="f64", comm=comm), ("E_theta", "E_beta", "a_theta", "b_beta")
+    if kind == "sgd":
+        from src.models.gaussian_mf_sgd import GaussianMFSGD, GaussianMFSGDConfig
+        return GaussianMFSGD(GaussianMFSGDConfig(n_factors=12, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0,
+                                                 lr=0.01, max_iter=4, tol=-1e9, verbose=False), dtype="f64", comm=comm), \
+            ("m_theta", "m_beta", "m_user_bias", "m_item_bias")
     from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
     return GaussianMFCAVI(GaussianMFCAVIConfig(n_factors=12, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0,
                                                max_iter=5, tol=-1.0, verbose=False), dtype="f64", comm=comm), \
@@ -48,7 +53,7 @@ def _build(kind, comm=None):
 
 
 def _fit(kind, model, train, val):
-    if kind == "gauss":
+    if kind in ("gauss", "sgd"):
         gm = float(train["rating"].mean())
         a, b = train.copy(), val.copy()
         a["rating"] -= gm; b["rating"] -= gm
@@ -100,7 +105,23 @@ def test_two_rank_fit_matches_single_process(kind, tmp_path):
                                        rtol=1e-8, atol=1e-11)
 
 
-@pytest.mark.parametrize("workload,chunks", [("gaussian_mf", 4), ("hpf_cavi", 4), ("gaussian_mf", 1)])
+def test_two_rank_gradient_mode_fit_is_consistent(tmp_path):
+    """The gradient mode averages the displacements of an item's pieces, so a sharded fit is a
+    different (equally valid) trajectory than the single-process one: the ranks must agree with
+    each other exactly and follow the same validation curve within 3 %."""
+    import torch.multiprocessing as mp
+    train, val = _data()
+    model, keys = _build("sgd")
+    _fit("sgd", model, train, val)
+    mp.spawn(_worker, args=(2, _free_port(), "sgd", str(tmp_path)), nprocs=2, join=True)
+    d0, d1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
+    for k in keys + ("pred", "val_rmse"):
+        assert np.array_equal(d0[k], d1[k]), k
+    assert int(d0["iters"]) == model.history_["iterations"] == 4
+    np.testing.assert_allclose(d0["val_rmse"], model.history_["val_rmse"], rtol=3e-2)
+
+
+@pytest.mark.parametrize("workload,chunks", [("gaussian_mf", 4), ("hpf_cavi", 4), ("gaussian_mf", 1), ("gaussian_mf_sgd", 4)])
 def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload, chunks):
     """bench.py launched as the driver launches it (torch.distributed.run, 2 ranks; gloo and one
     shared GPU stand in for RCCL over two): the replicated item state must end bit-identical on

@@ -51,7 +51,7 @@ struct SgdParams {
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void gauss_sgd_kernel(SgdParams<T> p) {
     constexpr int G = 256 / LPR;
-    constexpr int UN = LPR < 8 ? LPR : 8;   // gathers in flight per lane (they do not depend on the running row)
+    constexpr int UN = LPR < 8 ? LPR : 8;   // gathers in flight per lane (independent of the running row; 16 measured the same)
     const int c = threadIdx.x % LPR;
     const int64_t task_id = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
     if (task_id >= p.n_tasks) return;

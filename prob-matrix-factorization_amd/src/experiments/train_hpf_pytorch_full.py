@@ -71,6 +71,7 @@ def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=
     optimizer = torch.optim.Adam(model.parameters(), lr=lr, capturable=graph)
     if graph:
         static_idx, static_loss, step_graph = _graphed_step(model, optimizer, batch_size, u, i, r)
+    replays = 0
     for epoch in range(epochs):
         model.train()
         order = torch.randperm(n, device=r.device)
@@ -81,6 +82,7 @@ def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=
                 static_idx.copy_(idx)
                 step_graph.replay()
                 total += static_loss
+                replays += 1
                 continue
             optimizer.zero_grad()
             loss = model.loss(u[idx], i[idx], r[idx])
@@ -89,6 +91,7 @@ def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=
             total += loss.detach()
         if verbose and (epoch % log_every == 0 or epoch == epochs - 1):
             print(f"Epoch {epoch + 1}/{epochs} Loss: {total.item():.4f}")
+    model.training_info_ = {"graph_replays": replays, "steps": epochs * ((n + batch_size - 1) // batch_size)}
     return model
 
 

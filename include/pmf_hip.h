@@ -108,6 +108,22 @@ int pmf_ctx_destroy(pmf_ctx *ctx);
 int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream);
 int pmf_ctx_sync(pmf_ctx *ctx);
 
+/* HIP graphs (no reference counterpart).  At the reference's own problem sizes one iteration is a
+ * handful of launch-bound kernels: the sweep calls issued between pmf_graph_begin and pmf_graph_end
+ * are captured from the context's stream instead of being executed (their arguments are frozen),
+ * and pmf_graph_launch replays them.  The sequence must have run once before it is captured (lazily
+ * allocated arrays and scratch buffers cannot grow inside a capture), calls that synchronise or copy
+ * to the host cannot be captured, and profiling brackets are skipped inside a capture.
+ * pmf_graph_abort closes a capture after a failed call.  While a capture is open no other host thread may
+ * issue default-stream work on the device (HIP refuses it).  Measured gain at the reference's sizes: none
+ * (the iteration is bound by the kernels' dependent gather rounds); the model classes use it only with
+ * PMF_HIP_GRAPH=1. */
+int pmf_graph_begin(pmf_ctx *ctx);
+int pmf_graph_end(pmf_ctx *ctx, int *graph_id);
+int pmf_graph_abort(pmf_ctx *ctx);
+int pmf_graph_launch(pmf_ctx *ctx, int graph_id);
+int pmf_graph_destroy(pmf_ctx *ctx, int graph_id);
+
 /* Row chunks (no reference counterpart; multi-GPU pipelining).  `n_chunks` equal row ranges of
  * one side; the *_accumulate / *_finalize calls of that side then act on the chunk chosen with
  * pmf_ctx_select_chunk (-1 = all rows, the default) -- they read and write only rows

@@ -45,6 +45,8 @@ extern "C" int pmf_device_count(int *count) {
 // ---------------------------------------------------------------------------
 int pmf_dev_alloc(pmf_ctx *ctx, void **p, size_t bytes) {
     *p = nullptr;
+    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL,
+                "a device array would have to be allocated inside pmf_graph_begin / pmf_graph_end: run the sequence once before capturing it");
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {
@@ -63,6 +65,8 @@ void pmf_dev_free(pmf_ctx *ctx, void *p, size_t bytes) {
 
 static int grow(pmf_ctx *ctx, void **p, size_t *have, size_t want) {
     if (*have >= want) return PMF_OK;
+    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL,
+                "a scratch buffer would have to grow inside pmf_graph_begin / pmf_graph_end: run the sequence once before capturing it");
     if (*p) {
         PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         pmf_dev_free(ctx, *p, *have);
@@ -209,6 +213,7 @@ static void free_index(pmf_ctx *ctx) {
         free_tasks(ctx, ix.gamma_tasks);
         free_tasks(ctx, ix.gauss_tasks);
         free_tasks(ctx, ix.bias_tasks);
+        free_tasks(ctx, ix.sgd_tasks);
     }
     ctx->nnz = 0;
 }
@@ -231,6 +236,8 @@ extern "C" int pmf_ctx_destroy(pmf_ctx *ctx) {
         (void)hipEventDestroy(r.b);
     }
     for (auto &e : ctx->prof_pool) (void)hipEventDestroy(e);
+    for (auto &g : ctx->graphs)
+        if (g) (void)hipGraphExecDestroy(g);
     free_index(ctx);
     free_eval(ctx);
     for (int s = 0; s < 2; ++s)
@@ -249,6 +256,82 @@ extern "C" int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream) {
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
     PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PMF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// HIP graphs: at the reference's problem sizes an iteration is a handful of launch-bound kernels;
+// a sequence of sweep calls can be captured once from the context's stream and replayed
+// ---------------------------------------------------------------------------
+extern "C" int pmf_graph_begin(pmf_ctx *ctx) {
+    CHECK_CTX(ctx, "pmf_graph_begin");
+    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "pmf_graph_begin: a capture is already open");
+    PMF_HIP_CHECK(hipSetDevice(ctx->device));
+    PMF_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return PMF_OK;
+}
+
+static int end_capture(pmf_ctx *ctx, hipGraph_t *graph) {
+    ctx->capturing = false;
+    PMF_HIP_CHECK(hipStreamEndCapture(ctx->stream, graph));
+    return PMF_OK;
+}
+
+extern "C" int pmf_graph_abort(pmf_ctx *ctx) {
+    CHECK_CTX(ctx, "pmf_graph_abort");
+    if (!ctx->capturing) return PMF_OK;
+    hipGraph_t graph = nullptr;
+    int rc = end_capture(ctx, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return rc == PMF_OK ? PMF_OK : PMF_OK;   // the stream is usable again either way
+}
+
+extern "C" int pmf_graph_end(pmf_ctx *ctx, int *graph_id) {
+    CHECK_CTX(ctx, "pmf_graph_end");
+    PMF_REQUIRE(graph_id, PMF_EINVAL, "pmf_graph_end: null argument");
+    PMF_REQUIRE(ctx->capturing, PMF_EINVAL, "pmf_graph_end: no capture is open");
+    hipGraph_t graph = nullptr;
+    int rc = end_capture(ctx, &graph);
+    if (rc) return rc;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        pmf_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return PMF_EHIP;
+    }
+    try {
+        ctx->graphs.push_back(exec);
+    } catch (const std::bad_alloc &) {
+        (void)hipGraphExecDestroy(exec);
+        pmf_set_error("pmf_graph_end: out of host memory");
+        return PMF_ENOMEM;
+    }
+    *graph_id = (int)ctx->graphs.size() - 1;
+    return PMF_OK;
+}
+
+extern "C" int pmf_graph_launch(pmf_ctx *ctx, int graph_id) {
+    CHECK_CTX(ctx, "pmf_graph_launch");
+    PMF_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size() && ctx->graphs[(size_t)graph_id], PMF_EINVAL,
+                "pmf_graph_launch: unknown graph %d", graph_id);
+    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "pmf_graph_launch: a capture is open");
+    PMF_HIP_CHECK(hipSetDevice(ctx->device));
+    PMF_HIP_CHECK(hipGraphLaunch(ctx->graphs[(size_t)graph_id], ctx->stream));
+    return PMF_OK;
+}
+
+extern "C" int pmf_graph_destroy(pmf_ctx *ctx, int graph_id) {
+    CHECK_CTX(ctx, "pmf_graph_destroy");
+    PMF_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size(), PMF_EINVAL, "pmf_graph_destroy: unknown graph %d",
+                graph_id);
+    if (ctx->graphs[(size_t)graph_id]) {
+        PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipGraphExecDestroy(ctx->graphs[(size_t)graph_id]);
+        ctx->graphs[(size_t)graph_id] = nullptr;
+    }
     return PMF_OK;
 }
 
@@ -416,15 +499,28 @@ static int build_work_lists(pmf_ctx *ctx, int side) {
     free_tasks(ctx, ix.gamma_tasks);
     free_tasks(ctx, ix.gauss_tasks);
     free_tasks(ctx, ix.bias_tasks);
+    free_tasks(ctx, ix.sgd_tasks);
     const std::vector<int64_t> bounds = chunk_bounds(ctx, side);
     ix.nonempty_off.assign(bounds.size(), (int64_t)ix.h_nonempty.size());
     for (size_t g = 0; g + 1 < bounds.size(); ++g)
         ix.nonempty_off[g] = std::lower_bound(ix.h_nonempty.begin(), ix.h_nonempty.end(), (int32_t)bounds[g]) -
                              ix.h_nonempty.begin();
+    // A task is walked sequentially by one lane group / wavefront, so the longest task bounds the
+    // launch from below (C1: 256-rating tasks = 16 dependent gather rounds = 29 us for a 200k-rating
+    // sweep).  Small problems therefore get shorter tasks -- enough of them to occupy the chip -- and
+    // large ones keep the maximum, which minimises partial-sum traffic.  (Chunking only changes the
+    // summation order of rows longer than a chunk.)  The gradient mode has its own list with the fixed
+    // 256: its result is defined in terms of that piece length.
+    auto task_chunk = [&](int max_chunk) {
+        int64_t c = 32;
+        while (c < max_chunk && c * 65536 < ctx->nnz) c <<= 1;
+        return (int)c;
+    };
     int rc;
-    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAMMA_CHUNK, true, ix.gamma_tasks))) return rc;
-    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAUSS_CHUNK, false, ix.gauss_tasks))) return rc;
-    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAMMA_CHUNK, false, ix.bias_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, task_chunk(PMF_GAMMA_CHUNK), true, ix.gamma_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, task_chunk(PMF_GAUSS_CHUNK), false, ix.gauss_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, task_chunk(PMF_GAMMA_CHUNK), false, ix.bias_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAMMA_CHUNK, false, ix.sgd_tasks))) return rc;
     return PMF_OK;
 }
 
@@ -772,7 +868,7 @@ static hipEvent_t take_event(pmf_ctx *ctx) {
 }
 
 void pmf_prof_begin(pmf_ctx *ctx, int kernel) {
-    if (!ctx->prof) return;
+    if (!ctx->prof || ctx->capturing) return;
     pmf_ctx::ProfRec r;
     r.a = take_event(ctx);
     r.b = take_event(ctx);
@@ -782,7 +878,7 @@ void pmf_prof_begin(pmf_ctx *ctx, int kernel) {
 }
 
 void pmf_prof_end(pmf_ctx *ctx) {
-    if (!ctx->prof || ctx->prof_pending.empty()) return;
+    if (!ctx->prof || ctx->capturing || ctx->prof_pending.empty()) return;
     (void)hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
 }
 

@@ -90,7 +90,8 @@ struct PmfSideIndex {
     std::vector<int64_t> nonempty_off;  // [n_chunks + 1] offsets into d_nonempty
     PmfTaskList gamma_tasks;     // chunk = PMF_GAMMA_CHUNK, empty rows included
     PmfTaskList gauss_tasks;     // chunk = PMF_GAUSS_CHUNK, empty rows excluded
-    PmfTaskList bias_tasks;      // chunk = PMF_GAMMA_CHUNK, empty rows excluded
+    PmfTaskList bias_tasks;      // chunk <= PMF_GAMMA_CHUNK, empty rows excluded
+    PmfTaskList sgd_tasks;       // chunk = PMF_GAMMA_CHUNK exactly (the gradient mode is defined by it), empty rows excluded
 };
 
 struct PmfEvalSet {
@@ -131,6 +132,10 @@ struct pmf_ctx {
     size_t pinned_bytes = 0;
 
     int64_t device_bytes = 0;
+
+    // HIP graphs captured from sequences of sweep calls (pmf_graph_begin / _end)
+    bool capturing = false;
+    std::vector<hipGraphExec_t> graphs;
 
     bool prof = false;
     struct ProfRec {

@@ -175,7 +175,7 @@ int run_sgd(pmf_ctx *ctx, int side, int mode, void *stats, double lr, double sig
     if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gauss_sgd_sweep"))) return rc;
     if ((rc = pmf_require_array(ctx, other, PMF_ARR_FACTOR, "pmf_gauss_sgd_sweep"))) return rc;
     const bool bias = ctx->arr[0][PMF_ARR_BIAS] != nullptr && ctx->arr[1][PMF_ARR_BIAS] != nullptr;
-    const PmfTaskView tl = pmf_task_view(ctx, side, ix.bias_tasks, true);
+    const PmfTaskView tl = pmf_task_view(ctx, side, ix.sgd_tasks, true);
     SgdParams<T> p;
     p.tasks = tl.d_tasks;
     p.n_tasks = tl.n_tasks;

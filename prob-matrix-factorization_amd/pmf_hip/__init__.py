@@ -51,6 +51,11 @@ SIGNATURES = {
     "pmf_ctx_sgd_stats_width": (C.c_int, [_p, C.POINTER(C.c_int)]),
     "pmf_gauss_sgd_accumulate": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "pmf_gauss_sgd_finalize": (C.c_int, [_p, C.c_int, _p]),
+    "pmf_graph_begin": (C.c_int, [_p]),
+    "pmf_graph_end": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "pmf_graph_abort": (C.c_int, [_p]),
+    "pmf_graph_launch": (C.c_int, [_p, C.c_int]),
+    "pmf_graph_destroy": (C.c_int, [_p, C.c_int]),
     "pmf_ctx_set_row_chunks": (C.c_int, [_p, C.c_int, C.c_int]),
     "pmf_ctx_chunk_rows": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmf_ctx_select_chunk": (C.c_int, [_p, C.c_int, C.c_int]),

@@ -31,6 +31,12 @@ class Context:
         self.nnz = 0
         self.n_chunks = {USER: 1, ITEM: 1}
 
+    # ---- HIP graphs -------------------------------------------------------
+    def capture(self):
+        """`with ctx.capture() as g: <sweep calls>` records the calls instead of running them;
+        `g.launch()` replays them.  Run the same calls once normally first."""
+        return _Capture(self)
+
     # ---- row chunks (multi-GPU pipelining of a half-sweep) --------------
     def set_row_chunks(self, side, n_chunks):
         """Split `side`'s rows into equal ranges; accumulate / finalize calls then act on the
@@ -263,6 +269,27 @@ class Context:
             check(self._lib.pmf_prof_get(self._h, k, C.byref(ms), C.byref(n)), "pmf_prof_get")
             out[name] = (ms.value, n.value)
         return out
+
+
+class _Capture:
+    def __init__(self, ctx):
+        self._ctx, self.graph_id = ctx, None
+
+    def __enter__(self):
+        check(self._ctx._lib.pmf_graph_begin(self._ctx._h), "pmf_graph_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is not None:
+            self._ctx._lib.pmf_graph_abort(self._ctx._h)
+            return False
+        gid = C.c_int(-1)
+        check(self._ctx._lib.pmf_graph_end(self._ctx._h, C.byref(gid)), "pmf_graph_end")
+        self.graph_id = gid.value
+        return False
+
+    def launch(self):
+        check(self._ctx._lib.pmf_graph_launch(self._ctx._h, self.graph_id), "pmf_graph_launch")
 
 
 __all__ = ["Context", "PmfError", "USER", "ITEM"]

@@ -105,7 +105,7 @@ class GaussianHost(DeviceModel):
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
                 print(f"\n{self._iteration_label} {it}/{cfg.max_iter}")
-            self._iterate(ctx)
+            self._run_iteration(lambda: self._iterate(ctx))
             self._tick(it)
             if monitor is None:
                 continue

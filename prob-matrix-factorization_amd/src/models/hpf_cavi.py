@@ -93,7 +93,7 @@ class HPF_CAVI(DeviceModel):
             if cfg.verbose:
                 print(f"\nHPF_CAVI iteration {it}/{cfg.max_iter}")
             # theta then xi (hpf_cavi.py:126-159); beta then eta (hpf_cavi.py:162-193)
-            pdist.gamma_iteration(ctx, self._comm, stats, user_prior, item_prior)
+            self._run_iteration(lambda: pdist.gamma_iteration(ctx, self._comm, stats, user_prior, item_prior))
             self._tick(it)
             if monitor is None:
                 continue

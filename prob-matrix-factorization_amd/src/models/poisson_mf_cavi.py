@@ -70,7 +70,7 @@ class PoissonMFCAVI(DeviceModel):
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
             # users (poisson_mf_cavi.py:135-170) then items (:173-200); with a Comm the item
             # half-sweep is accumulate -> all-reduce -> finalize
-            pdist.gamma_iteration(ctx, self._comm, stats, prior, prior)
+            self._run_iteration(lambda: pdist.gamma_iteration(ctx, self._comm, stats, prior, prior))
             self._tick(it)
             if monitor is None:
                 continue

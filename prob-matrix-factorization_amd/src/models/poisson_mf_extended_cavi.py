@@ -77,8 +77,8 @@ class PoissonMFExtendedCAVI(DeviceModel):
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
-            ctx.gamma_ext_sweep(USER, cfg.a0, cfg.b0)   # poisson_mf_extended_cavi.py:108-160
-            ctx.gamma_ext_sweep(ITEM, cfg.a0, cfg.b0)   # poisson_mf_extended_cavi.py:163-215
+            self._run_iteration(lambda: (ctx.gamma_ext_sweep(USER, cfg.a0, cfg.b0),     # poisson_mf_extended_cavi.py:108-160
+                                         ctx.gamma_ext_sweep(ITEM, cfg.a0, cfg.b0)))    # poisson_mf_extended_cavi.py:163-215
             self._tick(it)
             if monitor is None:
                 continue

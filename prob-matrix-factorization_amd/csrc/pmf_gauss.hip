@@ -654,7 +654,8 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
 // flight per loop trip so that short rows (small K) still keep ~18 16-byte loads
 // per lane outstanding.  The MFMA blocks are folded into the packed image through
 // LDS once per task; a task that is a whole row is solved on the spot (FUSE).
-template <int KB, int NT, bool FUSE>
+// KS = register rows of the fused solve (8 / 16 for K <= 8 / 16: a quarter / half of the 32-row sweep).
+template <int KB, int NT, bool FUSE, int KS = KB>
 __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel(GaussParams<float> p, float inv_sigma2,
                                                                                 float inv_eta2, float *cov_self,
                                                                                 float *factor_self) {
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(256, KB == 64 ? 2 : 3) void gauss_accum_mfma_kernel
             }
         }
         wave_lds_fence();
-        solve_from_image<float, KB>(img, h ? whi : wlo, K, kpad, inv_sigma2, inv_eta2,
+        solve_from_image<float, KS>(img, h ? whi : wlo, K, kpad, inv_sigma2, inv_eta2,
                                     cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, lane);
         return;
     }
@@ -1049,12 +1050,12 @@ static bool use_bias(const pmf_ctx *ctx) {
 }
 
 // mode 0: fused (sums in place, then solve)   mode 1: accumulate into stats
-template <int KB, int NT>
+template <int KB, int NT, int KS = KB>
 static void launch_accum_mfma_nt(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, bool fuse, float is2, float ie2,
                                  float *cov, float *fac) {
     const size_t smem = (size_t)4 * ctx->cov_stride * sizeof(float);
     if (fuse)
-        hipLaunchKernelGGL((gauss_accum_mfma_kernel<KB, NT, true>), grid, dim3(256), smem, ctx->stream, p, is2, ie2, cov, fac);
+        hipLaunchKernelGGL((gauss_accum_mfma_kernel<KB, NT, true, KS>), grid, dim3(256), smem, ctx->stream, p, is2, ie2, cov, fac);
     else
         hipLaunchKernelGGL((gauss_accum_mfma_kernel<KB, NT, false>), grid, dim3(256), smem, ctx->stream, p, 0.f, 0.f,
                            (float *)nullptr, (float *)nullptr);
@@ -1064,7 +1065,11 @@ static void launch_accum_mfma_nt(pmf_ctx *ctx, const GaussParams<float> &p, dim3
 static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, bool fuse, float is2, float ie2,
                               float *cov, float *fac) {
     const int nt = (ctx->cov_stride / PMF_VEC + 63) / 64;  // 1..9
-    if (ctx->K <= 32) {
+    if (ctx->K <= 8) {
+        launch_accum_mfma_nt<32, 1, 8>(ctx, p, grid, fuse, is2, ie2, cov, fac);
+    } else if (ctx->K <= 16) {
+        launch_accum_mfma_nt<32, 1, 16>(ctx, p, grid, fuse, is2, ie2, cov, fac);
+    } else if (ctx->K <= 32) {
         switch (nt) {
             case 1: launch_accum_mfma_nt<32, 1>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
             case 2: launch_accum_mfma_nt<32, 2>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;

@@ -1075,6 +1075,12 @@ static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 gr
             case 2: launch_accum_mfma_nt<32, 2>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
             default: launch_accum_mfma_nt<32, 3>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
         }
+    } else if (ctx->K <= 48) {   // Kp <= 1176: 3..5 chunk columns; a 48-row sweep instead of the 64-row one
+        switch (nt) {
+            case 3: launch_accum_mfma_nt<64, 3, 48>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 4: launch_accum_mfma_nt<64, 4, 48>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            default: launch_accum_mfma_nt<64, 5, 48>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+        }
     } else {
         switch (nt) {
             case 3: launch_accum_mfma_nt<64, 3>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;

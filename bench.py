@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: ratings/s per CAVI epoch on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload gaussian_mf|hpf_cavi]
+    python bench.py --gpus N --steps K --warmup W [--workload gaussian_mf|hpf_cavi|...]
 
 A "step" is one full CAVI iteration (all half-sweeps of the model) over the
 synthetic rating matrix of SURVEY.md section 8(d).  The default workload is
 BASELINE.json configs[1]: Gaussian MF (mean-field CAVI with user/item biases,
 the reference's `gaussian_mf_cavi_bias.GaussianMFCAVI`), K = 64, 1M users x
-100k items, 50M ratings, on one GPU.  With N > 1 (launched by torch.distributed.run,
-one rank per GPU) every rank holds its own 1M-user / 50M-rating shard (weak
-scaling), the item block is replicated and the per-item sufficient statistics
-are all-reduced over RCCL once per item half-sweep.
+100k items, 50M ratings.
+
+N > 1 (one process per GPU, started by `python -m torch.distributed.run` or any
+launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT) STRONG-scales that
+one matrix, as the north star asks and as the reference times it (one dataset, one
+`fit`: compare_models.py:87-92): the ratings are sharded by user range, the item
+block is replicated and the per-item sufficient statistics are all-reduced over
+RCCL once per item half-sweep -- inside libpmf_hip.so (pmf_comm_init).  `--scaling
+weak` gives every rank its own 1M-user / 50M-rating shard instead.  This program
+never imports torch (`config.torch_imported`).
 
 Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
-`roofline` (dominant kernel: algorithmic bytes / live hipEvent time vs the 8 TB/s
-HBM peak) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
+`roofline` (dominant kernel: algorithmic bytes / live hipEvent time vs its bound)
+and `cpu_baseline` (the CPU oracle timed on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,21 +42,21 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 WORKLOADS = {
-    # name: (n_users, n_items, nnz) per GPU, K, hyper-parameters (best_hyperparams.txt:3,5)
+    # name: (n_users, n_items, nnz), K, hyper-parameters (best_hyperparams.txt:3,5)
     "gaussian_mf": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
                         hp=dict(sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0),
-                        label="gaussian_mf_cavi_bias K=64, 1Mx100k synthetic, 50M ratings per GPU"),
+                        label="gaussian_mf_cavi_bias K=64, 1Mx100k synthetic, 50M ratings"),
     # BASELINE configs[3] per-GPU shard (10M x 1M, 500M ratings over 8 GPUs), K = 128
     "gaussian_mf_k128": dict(U=1_250_000, I=1_000_000, N=62_500_000, K=128,
                              hp=dict(sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0),
-                             label="gaussian_mf_cavi_bias K=128, 1.25Mx1M synthetic, 62.5M ratings per GPU"),
+                             label="gaussian_mf_cavi_bias K=128, 1.25Mx1M synthetic, 62.5M ratings"),
     "hpf_cavi": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
                      hp=dict(a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0),
-                     label="hpf_cavi K=64, 1Mx100k synthetic, 50M ratings per GPU"),
+                     label="hpf_cavi K=64, 1Mx100k synthetic, 50M ratings"),
     # MAP / gradient mode of the Gaussian model (no reference counterpart, parity unpinned)
     "gaussian_mf_sgd": dict(U=1_000_000, I=100_000, N=50_000_000, K=64,
                             hp=dict(lr=0.01, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0),
-                            label="gaussian_mf MAP by gradient steps K=64, 1Mx100k synthetic, 50M ratings per GPU"),
+                            label="gaussian_mf MAP by gradient steps K=64, 1Mx100k synthetic, 50M ratings"),
 }
 SMALL = dict(U=100_000, I=10_000, N=5_000_000)  # --small: quick functional run
 
@@ -75,19 +82,37 @@ def algorithmic_bytes(workload, U, I, N, K, elem=4):
     return total, total
 
 
+def host_cpu():
+    """(model string, logical cores) of the box the CPU baseline runs on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([int(p.get("num_threads", 1)) for p in threadpool_info()] or [1])
+    except Exception:  # pragma: no cover
+        return 1
+
+
 def cpu_baseline(workload, K, hp, device=0):
-    """The CPU oracle's per-row loop (the reference's loop structure) on a
-    bounded sample of the same generator: ~10-30 s of single-thread CPU work.
-    The engine then runs the same iteration on the same sample, so the line also
+    """The CPU oracle's per-row loop (the reference's loop structure) on a bounded sample of
+    the same generator: ~10-30 s of CPU work with NumPy's default BLAS threading (`cores` = the
+    threads its pool holds; the loop itself is interpreter-bound, one row at a time, as in the
+    reference).  The engine then runs the same iteration on the same sample, so the line also
     carries the second half of BASELINE.json's metric ("val RMSE vs CPU ref")."""
     from oracle import cavi_oracle as orc
     import pmf_hip
     from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER
     from pmf_hip.synth import synth_ratings, train_val_split
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
     gauss = workload.startswith("gaussian_mf")
     if gauss:
         U, I, N = (20_000, 2_000, 1_100_000) if K <= 64 else (3_000, 300, 110_000)
@@ -125,27 +150,22 @@ def cpu_baseline(workload, K, hp, device=0):
             ctx.gamma_sweep(ITEM, hp["c"], 0.0, True, st["gamma_a_eta"], hp["d_prime"])
             pred_gpu = ctx.predict(vu, vi)
 
-    def run():
-        t0 = time.perf_counter()
-        if gauss:
-            orc.gaussian_iteration(st, idx, u, i, x, hp["sigma2"], hp["eta_theta2"], hp["eta_beta2"], hp["eta_bias2"])
-        else:
-            orc.hpf_iteration(st, idx, u, i, x, hp["a"], hp["b_prime"], hp["c"], hp["d_prime"])
-        return time.perf_counter() - t0
-
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            dt = run()
+    t0 = time.perf_counter()
+    if gauss:
+        orc.gaussian_iteration(st, idx, u, i, x, hp["sigma2"], hp["eta_theta2"], hp["eta_beta2"], hp["eta_bias2"])
     else:
-        dt = run()
+        orc.hpf_iteration(st, idx, u, i, x, hp["a"], hp["b_prime"], hp["c"], hp["d_prime"])
+    dt = time.perf_counter() - t0
     if gauss:
         pred_cpu = orc.predict_dot(st["m_theta"], st["m_beta"], vu, vi, st["m_user_bias"], st["m_item_bias"])
     else:
         pred_cpu = orc.predict_dot(st["E_theta"], st["E_beta"], vu, vi)
     rm_cpu, rm_gpu = orc.rmse(vy, pred_cpu), orc.rmse(vy, pred_gpu)
-    out = {"value": N / dt, "unit": "ratings/s", "cores": 1, "kind": "port",
+    model, logical = host_cpu()
+    out = {"value": N / dt, "unit": "ratings/s", "cores": blas_threads(), "kind": "port",
            "sample": f"1 iteration of the oracle's per-row NumPy loop, {U}x{I}, {N} ratings, K={K} "
-                     f"(same generator), {dt:.1f} s",
+                     f"(same generator), {dt:.1f} s, default BLAS threading",
+           "cpu_model": model, "logical_cores": logical,
            "val_rmse_cpu": rm_cpu, "val_rmse_gpu_f32": rm_gpu, "val_rmse_abs_diff": abs(rm_cpu - rm_gpu)}
     if not gauss:
         # "best-effort CPU" (BASELINE.md section 3): the same iteration as whole-array NumPy
@@ -169,18 +189,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="gaussian_mf")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = shard the one fixed matrix by user range (default, the north star's "
+                         "problem); weak = every rank its own full-size shard")
     ap.add_argument("--small", action="store_true", help="1/10 size functional run (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--only", action="store_true", help="skip the secondary HPF-CAVI measurement of the default run")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
-                    "rehearse the multi-rank path on a single-GPU box)")
+    ap.add_argument("--only", action="store_true", help="skip the secondary measurements (HPF-CAVI, f64) of the default run")
+    ap.add_argument("--transport", choices=["rccl", "hostshm"], default=os.environ.get("PMF_COMM_TRANSPORT", "rccl"),
+                    help="rccl = one rank per GPU over xGMI; hostshm = rehearsal transport for ranks sharing one GPU")
     ap.add_argument("--chunks", type=int, default=None, help="item row chunks of the pipelined item half-sweep at "
-                    "N > 1 (default PMF_DIST_CHUNKS or 4; 1 = accumulate, then all-reduce, then finalize)")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0")
+                    "N > 1 (default PMF_DIST_CHUNKS or by message size; 1 = accumulate, then all-reduce, then finalize)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0 (needs --transport hostshm)")
     ap.add_argument("--factors", type=int, default=None, help="exploration: override the workload's K")
     args = ap.parse_args()
 
-    import torch
     import pmf_hip
     from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER, dist as pdist
     from pmf_hip.synth import BASE_SEED, synth_ratings
@@ -189,19 +211,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
     if args.share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    comm = None
-    if world > 1:
-        import torch.distributed as tdist
-        if args.backend == "nccl":
-            tdist.init_process_group(backend="nccl", device_id=device)
-        else:
-            tdist.init_process_group(backend=args.backend)
-        comm = pdist.Comm()
+    comm = pdist.init_from_env(device=local_rank, transport=args.transport) if world > 1 else None
+    strong = args.scaling == "strong"
 
     w = dict(WORKLOADS[args.workload])
     if args.small:
@@ -210,86 +225,93 @@ def main():
         w["K"] = args.factors
         w["label"] += f" [K overridden to {args.factors}]"
     U, I, N, K, hp = w["U"], w["I"], w["N"], w["K"], w["hp"]
-    elem = 4 if args.dtype == "f32" else 8
 
     # ---- data (untimed) ----------------------------------------------------
     t0 = time.time()
-    # every rank draws its own users / ratings over the same item catalogue
-    u, i, r = synth_ratings(U, I, N, seed=BASE_SEED + rank, item_seed=(BASE_SEED if world > 1 else None))
+    lo = 0
+    if comm is not None and strong:
+        # ONE matrix: every rank draws the same ratings and keeps the ones of its user range
+        u, i, r = synth_ratings(U, I, N, seed=BASE_SEED)
+        bounds = pdist.shard_bounds(u, U, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        u, i, r = pdist.take_shard(u, i, r, bounds, rank)
+        U_loc = hi - lo
+    else:
+        # weak scaling: every rank draws its own users / ratings over the same item catalogue
+        u, i, r = synth_ratings(U, I, N, seed=BASE_SEED + rank, item_seed=(BASE_SEED if world > 1 else None))
+        U_loc = U
+    N_loc = len(u)
     t_gen = time.time() - t0
+    if comm is not None:
+        n_all = comm.all_reduce_host([float(N_loc), float(U_loc)])
+        ratings_total, users_total = int(n_all[0]), int(n_all[1])
+        centre = float(comm.all_reduce_host([float(r.sum())])[0]) / ratings_total   # the global train mean
+    else:
+        ratings_total, users_total, centre = N_loc, U_loc, float(r.mean())
 
-    def fence():
-        if comm is not None:
-            comm.barrier()
-        torch.cuda.synchronize()
-
-    def run(workload, hp, steps, warmup):
+    def run(workload, hp, steps, warmup, dtype):
         """Build the device state of `workload` on the shared ratings, run warmup + timed steps
-        (barrier + synchronize on both sides, max over ranks) and return the measurements."""
+        (device sync + barrier on both sides, max over ranks) and return the measurements."""
+        elem = 4 if dtype == "f32" else 8
         sgd = workload == "gaussian_mf_sgd"
         gauss = workload.startswith("gaussian_mf") and not sgd
-        ctx = pmf_hip.Context(U, I, K, dtype=args.dtype, device=local_rank)
-        # kernels, RCCL collectives and torch allocations share one non-default stream
-        scope = pdist.StreamScope(ctx, device).enter()
+        ctx = pmf_hip.Context(U_loc, I, K, dtype=dtype, device=local_rank)
         if comm is not None:
+            comm.attach(ctx)     # ITEM half-sweeps: accumulate -> RCCL all-reduce -> finalize inside the library
             n_chunks = args.chunks or pdist.default_item_chunks(world, pdist.item_message_bytes(ctx, gauss))
             ctx.set_row_chunks(ITEM, n_chunks)
+
+        def fence():
+            ctx.sync()
+            if comm is not None:
+                comm.barrier()
+
         rng = np.random.default_rng(42)
         t0 = time.time()
         if gauss or sgd:
-            ctx.set_ratings(u, i, r - float(r.mean()))  # centred as compare_models.py:54-65
+            ctx.set_ratings(u, i, r - centre)           # centred as compare_models.py:54-65
         else:
             ctx.set_ratings(u, i, r + 1.0)              # +1 shift as compare_models.py:180-185
         t_csr = time.time() - t0
-        stats_item = stats_bias = None
-        if gauss:
-            # gaussian_mf_cavi_bias.py:52-67 initial state
-            init_u, init_i = 0.1 * rng.standard_normal((U, K)), 0.1 * np.random.default_rng(43).standard_normal((I, K))
+        mine = slice(lo, lo + U_loc) if (comm is not None and strong) else slice(0, U_loc)
+        draw_u = U if (comm is not None and strong) else U_loc
+        if gauss or sgd:
+            # gaussian_mf_cavi_bias.py:52-67 initial state (item draws from their own stream: replicas agree)
+            init_u = (0.1 * rng.standard_normal((draw_u, K)))[mine]
+            init_i = 0.1 * np.random.default_rng(43).standard_normal((I, K))
             t0 = time.time()
             ctx.set_array(USER, ARR_FACTOR, init_u)
             ctx.set_array(ITEM, ARR_FACTOR, init_i)
-            ctx.set_cov_identity(USER, 1.0)
-            ctx.set_cov_identity(ITEM, 1.0)
-            ctx.set_array(USER, ARR_BIAS, np.zeros(U))
+            if gauss:
+                ctx.set_cov_identity(USER, 1.0)
+                ctx.set_cov_identity(ITEM, 1.0)
+            ctx.set_array(USER, ARR_BIAS, np.zeros(U_loc))
             ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
-            if comm is not None:
-                stats_item, stats_bias = pdist.gauss_stats(ctx, device)
-
-            def step():
-                pdist.gaussian_iteration(ctx, comm, stats_item, stats_bias, hp["sigma2"], hp["eta_theta2"],
-                                         hp["eta_beta2"], hp["eta_bias2"])
-            dominant = "gauss_accum"
-        elif sgd:
-            init_u, init_i = 0.1 * rng.standard_normal((U, K)), 0.1 * np.random.default_rng(43).standard_normal((I, K))
-            t0 = time.time()
-            ctx.set_array(USER, ARR_FACTOR, init_u)
-            ctx.set_array(ITEM, ARR_FACTOR, init_i)
-            ctx.set_array(USER, ARR_BIAS, np.zeros(U))
-            ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
-            if comm is not None:
-                stats_item = pdist.sgd_stats(ctx, device)
-
-            def step():
-                pdist.gaussian_sgd_iteration(ctx, comm, stats_item, hp["lr"], hp["sigma2"], hp["eta_theta2"],
-                                             hp["eta_beta2"], hp["eta_bias2"])
-            dominant = "gauss_sgd"
+            if gauss:
+                def step():
+                    pdist.gaussian_iteration(ctx, comm, None, None, hp["sigma2"], hp["eta_theta2"], hp["eta_beta2"],
+                                             hp["eta_bias2"])
+                dominant = "gauss_accum"
+            else:
+                def step():
+                    pdist.gaussian_sgd_iteration(ctx, comm, None, hp["lr"], hp["sigma2"], hp["eta_theta2"],
+                                                 hp["eta_beta2"], hp["eta_bias2"])
+                dominant = "gauss_sgd"
         else:
             # hpf_cavi.py:66-89 initial state
-            init_u = (hp["a"] + rng.gamma(1.0, 0.1, (U, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (U, K)))
+            init_u = ((hp["a"] + rng.gamma(1.0, 0.1, (draw_u, K))) / (hp["b_prime"] + rng.gamma(1.0, 0.1, (draw_u, K))))[mine]
             r2 = np.random.default_rng(43)
             init_i = (hp["c"] + r2.gamma(1.0, 0.1, (I, K))) / (hp["d_prime"] + r2.gamma(1.0, 0.1, (I, K)))
             t0 = time.time()
             ctx.set_array(USER, ARR_FACTOR, init_u)
             ctx.set_array(ITEM, ARR_FACTOR, init_i)
-            ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, (hp["a_prime"] + K * hp["a"]) / hp["b_prime"]))
+            ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U_loc, (hp["a_prime"] + K * hp["a"]) / hp["b_prime"]))
             ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, (hp["c_prime"] + K * hp["c"]) / hp["d_prime"]))
-            if comm is not None:
-                stats_item = pdist.gamma_stats(ctx, device)
             up = (hp["a"], 0.0, True, hp["a_prime"] + K * hp["a"], hp["b_prime"])
             ip = (hp["c"], 0.0, True, hp["c_prime"] + K * hp["c"], hp["d_prime"])
 
             def step():
-                pdist.gamma_iteration(ctx, comm, stats_item, up, ip)
+                pdist.gamma_iteration(ctx, comm, None, up, ip)
             dominant = "gamma_sweep"
 
         ctx.sync()
@@ -307,83 +329,117 @@ def main():
         prof = ctx.prof_get()
         ctx.prof_enable(False)
         if comm is not None:
-            import torch.distributed as tdist
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed = float(comm.all_reduce_host([elapsed], op="max")[0])
         t0 = time.time()
         ctx.get_array(USER, ARR_FACTOR)
-        ctx.get_array(ITEM, ARR_FACTOR)
+        item_factors = ctx.get_array(ITEM, ARR_FACTOR)
         t_pull = time.time() - t0
         consistent = None
         if comm is not None:
             # outside the timed region: the replicated item state must be bit-identical on all ranks
-            import hashlib
-            import torch.distributed as tdist
-            digest = hashlib.sha256(ctx.get_array(ITEM, ARR_FACTOR).tobytes()).digest()[:8]
-            mine = torch.tensor(list(digest), dtype=torch.int64, device=device)
-            every = [torch.empty_like(mine) for _ in range(world)]
-            tdist.all_gather(every, mine)
-            consistent = all(bool((e == mine).all().item()) for e in every)
+            digest = np.frombuffer(hashlib.sha256(item_factors.tobytes()).digest()[:8], dtype=np.uint8).astype(np.float64)
+            top, bottom = comm.all_reduce_host(digest, op="max"), -comm.all_reduce_host(-digest, op="max")
+            consistent = bool(np.array_equal(top, bottom))
             if not consistent:
                 raise RuntimeError(f"{workload}: the replicated item state differs between ranks -- the "
                                    "item half-sweep and its collective are not ordered; the rate would be meaningless")
-        total_bytes, dom_bytes = algorithmic_bytes(workload, U, I, N, K, elem)
+        del item_factors
+        # roofline of the dominant kernel: this rank's launches against this rank's algorithmic bytes
+        total_bytes, dom_bytes = algorithmic_bytes(workload, U_loc, I, N_loc, K, elem)
+        whole_bytes, _ = algorithmic_bytes(workload, users_total if strong or comm is None else U_loc * world, I,
+                                           ratings_total, K, elem)
         dom_ms, dom_n = prof[dominant]
         achieved = dom_bytes / (dom_ms / steps * 1e-3) / 1e9 if dom_n else 0.0  # bytes per epoch / kernel time per epoch
-        traffic = None
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom_ms / max(dom_n, 1),
+                    "launches": dom_n}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and not args.small and args.dtype == "f32" and not args.factors:
-            try:
-                traffic = json.load(open(tpath)).get(f"{workload}:{dominant}")
+        if os.path.exists(tpath) and not args.small and dtype == "f32" and not args.factors and comm is None:
+            try:   # PMC bytes per launch from the committed rocprofv3 --pmc passes of this command, not measured in this run
+                roofline["traffic"] = json.load(open(tpath)).get(f"{workload}:{dominant}")
+                roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of this workload; static)"
             except Exception:
-                traffic = None
+                pass
+        if dominant == "gamma_sweep" and comm is None:
+            # The gathered tables live in L2 / Infinity Cache (25.6 MB of item rows, 256 MB of user rows), so HBM
+            # does not bound this kernel: its roofline is what the cache hierarchy delivers for this gather
+            # pattern, measured live by the kernel's gather-only twin on the same ratings and tables.
+            side_bytes = {USER: N_loc * (elem * K + 8) + U_loc * 4 * elem * K, ITEM: N_loc * (elem * K + 8) + I * 4 * elem * K}
+            ceil_ms = {s: ctx.gather_ceiling_ms(s, 5) for s in (USER, ITEM)}
+            peak = sum(side_bytes.values()) / (sum(ceil_ms.values()) * 1e-3) / 1e9
+            # compulsory DRAM traffic: index + rating streams, row I/O, each gathered table read once
+            dram = 2 * N_loc * 8 + (U_loc + I) * 4 * elem * K + (U_loc + I) * elem * K
+            roofline.update({
+                "bound": "cache_gather", "peak": peak, "frac": achieved / peak,
+                "peak_source": "pmf_prof_gather_ceiling: the sweep kernel's memory side alone on the same ratings/tables, "
+                               "live in this run (user side %.3f ms, item side %.3f ms per launch)" % (ceil_ms[USER], ceil_ms[ITEM]),
+                "algorithmic_GBps": achieved, "frac_of_hbm_peak_algorithmic": achieved / HBM_PEAK_GBS,
+                "compulsory_dram_GBps": dram / (dom_ms / steps * 1e-3) / 1e9,
+                "compulsory_dram_frac_of_hbm_peak": dram / (dom_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS})
         res = {
-            "value": world * N * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-            "epoch_algorithmic_GB": total_bytes / 1e9,
-            "epoch_fraction_of_hbm_roofline": (total_bytes / (elapsed / steps)) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n},
+            "value": (ratings_total if strong or comm is None else N_loc * world) * steps / elapsed,
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "epoch_algorithmic_GB": whole_bytes / 1e9,
+            "epoch_algorithmic_GBps": whole_bytes / (elapsed / steps) / 1e9,
+            "roofline": roofline,
             "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
             "csr_build_and_upload_s": t_csr, "state_upload_s": t_state, "factor_download_s": t_pull,
             "device_GB": ctx.device_bytes() / 1e9,
             "item_replicas_identical": consistent, "item_chunks": ctx.n_chunks[ITEM],
         }
-        scope.exit()
+        if comm is not None:
+            # compute-stream idle time waiting for a chunk's all-reduce = communication NOT hidden behind kernels
+            res["comm_exposed_ms"] = prof["comm_wait"][0] / steps
+            res["comm_allreduce_ms"] = prof["comm_allreduce"][0] / steps
         ctx.close()
-        del stats_item, stats_bias
-        torch.cuda.empty_cache()
         return res
 
     gauss = args.workload.startswith("gaussian_mf")
-    main_res = run(args.workload, hp, args.steps, args.warmup)
-    also = None
+    main_res = run(args.workload, hp, args.steps, args.warmup, args.dtype)
+    also = {}
     if args.workload == "gaussian_mf" and not args.only:
         # the north star names both models: HPF-CAVI on the same ratings (+1), same protocol
-        also = run("hpf_cavi", WORKLOADS["hpf_cavi"]["hp"], max(args.steps, 10), max(args.warmup, 2))
+        also["hpf_cavi"] = run("hpf_cavi", WORKLOADS["hpf_cavi"]["hp"], max(args.steps, 10), max(args.warmup, 2), args.dtype)
+        if comm is None and args.dtype == "f32":
+            # the reference's own arithmetic is float64: both models in the engine's f64 (parity) mode
+            also["f64"] = {"gaussian_mf": run("gaussian_mf", hp, 3, 1, "f64"),
+                           "hpf_cavi": run("hpf_cavi", WORKLOADS["hpf_cavi"]["hp"], 5, 1, "f64")}
     del u, i, r
 
     if rank != 0:
-        if comm is not None:
-            comm.barrier()
-            import torch.distributed as tdist
-            tdist.destroy_process_group()
+        comm.barrier()
+        comm.close()
         return
 
+    def brief(res, metric, dtype):
+        out = {"metric": metric, "unit": "ratings/s", "dtype": dtype, "value": res["value"], "ms_per_step": res["ms_per_step"],
+               "steps": res["steps"], "epoch_algorithmic_GBps": res["epoch_algorithmic_GBps"], "roofline": res["roofline"],
+               "kernels_ms_per_step": res["kernels_ms_per_step"]}
+        for k in ("comm_exposed_ms", "comm_allreduce_ms"):
+            if k in res:
+                out[k] = res[k]
+        return out
+
+    per_gpu = " per GPU" if (world > 1 and not strong) else ""
     out = {
         "metric": (f"ratings/sec (epoch) Gaussian-MF MAP/SGD K={K}" if args.workload == "gaussian_mf_sgd" else
                    f"ratings/sec (epoch) Gaussian-MF K={K}" if gauss else f"ratings/sec (epoch) HPF-CAVI K={K}"),
         "value": main_res["value"], "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": w["label"] + (" [--small]" if args.small else ""), "n_users_per_gpu": U,
-                   "n_items": I, "ratings_per_gpu": N, "n_factors": K,
-                   "parallelism": f"user-range rating shards x{world}, item statistics all-reduce ({args.backend}) "
-                                  f"pipelined over {main_res['item_chunks']} item chunks"
-                                  if world > 1 else "single GPU",
+        "config": {"workload": w["label"] + per_gpu + (" [--small]" if args.small else ""),
+                   "n_users": users_total, "n_items": I, "ratings_total": ratings_total, "n_factors": K,
+                   "ratings_on_rank0": N_loc, "users_on_rank0": U_loc,
+                   "parallelism": (f"user-range rating shards x{world} of the one matrix, item statistics all-reduced inside "
+                                   f"libpmf_hip.so ({args.transport}), pipelined over {main_res['item_chunks']} item chunks"
+                                   if world > 1 and strong else
+                                   f"one full-size user shard per rank x{world}, item statistics all-reduced inside "
+                                   f"libpmf_hip.so ({args.transport}), pipelined over {main_res['item_chunks']} item chunks"
+                                   if world > 1 else "single GPU"),
                    "epoch_algorithmic_GB": main_res["epoch_algorithmic_GB"],
-                   "epoch_fraction_of_hbm_roofline": main_res["epoch_fraction_of_hbm_roofline"]},
+                   "epoch_algorithmic_GBps": main_res["epoch_algorithmic_GBps"],
+                   "torch_imported": "torch" in sys.modules},
         "roofline": main_res["roofline"],
         "kernels_ms_per_step": main_res["kernels_ms_per_step"],
         # host-buffer legs of the boundary (never part of `value`): ratings upload + index build,
@@ -394,20 +450,23 @@ def main():
     }
     if world > 1:
         out["config"]["item_replicas_identical"] = main_res["item_replicas_identical"]
-    if also is not None:
-        out["also"] = {"hpf_cavi": {"metric": f"ratings/sec (epoch) HPF-CAVI K={K}", "unit": "ratings/s",
-                                    "value": also["value"], "ms_per_step": also["ms_per_step"], "steps": also["steps"],
-                                    "epoch_fraction_of_hbm_roofline": also["epoch_fraction_of_hbm_roofline"],
-                                    "roofline": also["roofline"]}}
+        out["comm_exposed_ms"] = main_res["comm_exposed_ms"]
+        out["comm_allreduce_ms"] = main_res["comm_allreduce_ms"]
+    if also:
+        out["also"] = {}
+        if "hpf_cavi" in also:
+            out["also"]["hpf_cavi"] = brief(also["hpf_cavi"], f"ratings/sec (epoch) HPF-CAVI K={K}", args.dtype)
+        if "f64" in also:
+            out["also"]["f64"] = {"gaussian_mf": brief(also["f64"]["gaussian_mf"], f"ratings/sec (epoch) Gaussian-MF K={K}", "f64"),
+                                  "hpf_cavi": brief(also["f64"]["hpf_cavi"], f"ratings/sec (epoch) HPF-CAVI K={K}", "f64")}
     if not args.no_cpu_baseline and world == 1 and args.workload != "gaussian_mf_sgd":
         out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank)
-        if also is not None:
+        if "hpf_cavi" in also:
             out["also"]["hpf_cavi"]["cpu_baseline"] = cpu_baseline("hpf_cavi", K, WORKLOADS["hpf_cavi"]["hp"], local_rank)
     print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()
-        import torch.distributed as tdist
-        tdist.destroy_process_group()
+        comm.close()
 
 
 if __name__ == "__main__":

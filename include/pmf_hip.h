@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMF_ABI_VERSION 1
+#define PMF_ABI_VERSION 2
 
 /* error codes */
 #define PMF_OK 0
@@ -37,6 +37,7 @@ extern "C" {
 #define PMF_EHIP (-2)     /* a HIP runtime call failed (message has the hipError string) */
 #define PMF_ENOMEM (-3)
 #define PMF_ERANGE (-4)   /* id outside [0, n_rows) or unsupported n_factors */
+#define PMF_ECOMM (-5)    /* a collective / communicator call failed (RCCL error string in the message) */
 
 /* device storage / arithmetic type of a context */
 #define PMF_F32 0
@@ -83,7 +84,9 @@ extern "C" {
 #define PMF_KERNEL_TOPK 7
 #define PMF_KERNEL_GAUSS_COMBINE 8 /* split-row partial sums -> row sums */
 #define PMF_KERNEL_GAUSS_SGD 9     /* MAP gradient half-sweep (no reference counterpart) */
-#define PMF_KERNEL_COUNT 10
+#define PMF_KERNEL_COMM_ALLREDUCE 10 /* item-statistics all-reduce, timed on the collective stream */
+#define PMF_KERNEL_COMM_WAIT 11    /* compute stream idle until a chunk's all-reduce has landed = exposed communication */
+#define PMF_KERNEL_COUNT 12
 
 typedef struct pmf_ctx pmf_ctx;
 
@@ -222,6 +225,49 @@ int pmf_gauss_bias_accumulate(pmf_ctx *ctx, int side, void *stats_dev);
 int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sigma2,
                             double eta_bias2);
 
+/* ---- multi-GPU: RCCL inside the library (SURVEY.md section 8(b) `pmf_comm_init`, section 8(e)) ------
+ * No reference counterpart (the reference is a single process).  One process per GPU; ratings are
+ * sharded by USER RANGE (the context's n_users is this rank's range, ids local to it), the item block
+ * is replicated.  Once a context has a communicator (of any size), every ITEM-side half-sweep
+ * (pmf_gamma_sweep, pmf_gauss_factor_sweep, pmf_gauss_bias_sweep, pmf_gauss_sgd_sweep with
+ * side = PMF_SIDE_ITEM) runs inside the library as
+ *     accumulate raw per-item sums over this rank's ratings  ->  all-reduce (sum)  ->  finalize
+ * on a library-owned statistics buffer, pipelined over the item row chunks of pmf_ctx_set_row_chunks:
+ * the all-reduce of chunk c runs on a second, high-priority HIP stream (ordered against the compute
+ * stream by events, never by the host) while chunk c+1 is accumulated.  Per-row arithmetic is that of
+ * the accumulate / finalize pair, so results do not depend on the chunking, and every rank ends the
+ * half-sweep with bit-identical item state.  USER-side half-sweeps stay local.  The iteration order a
+ * caller issues is unchanged (gaussian_mf_cavi_bias.py:129-263, hpf_cavi.py:121-193).
+ * pmf_gamma_ext_sweep is not available with a communicator.
+ *
+ * pmf_comm_unique_id: 128 bytes from ncclGetUniqueId; rank 0 creates them and hands them to the other
+ * ranks out of band (pmf_hip/dist.py: a file next to the launcher's rendezvous).  pmf_comm_init: RCCL
+ * communicator over xGMI, collective (every rank must call it).  pmf_comm_init_hostshm: same
+ * interface over POSIX shared memory for ranks that share ONE GPU -- a rehearsal transport for
+ * one-GPU boxes (RCCL refuses two ranks per device), never a production path.  pmf_comm_attach lets a
+ * second context of the same process and device share `owner`'s communicator; pmf_comm_destroy
+ * detaches (the communicator goes with its last user; pmf_ctx_destroy detaches too). */
+#define PMF_UNIQUE_ID_BYTES 128
+#define PMF_TRANSPORT_RCCL 0
+#define PMF_TRANSPORT_HOSTSHM 1
+#define PMF_OP_SUM 0
+#define PMF_OP_MAX 1
+int pmf_comm_unique_id(void *id_out);
+int pmf_comm_init(pmf_ctx *ctx, int nranks, int rank, const void *unique_id);
+int pmf_comm_init_hostshm(pmf_ctx *ctx, int nranks, int rank, const void *unique_id);
+int pmf_comm_attach(pmf_ctx *ctx, pmf_ctx *owner);
+int pmf_comm_destroy(pmf_ctx *ctx);
+int pmf_comm_info(pmf_ctx *ctx, int *nranks, int *rank, int *transport);
+/* all queued work of every rank (kernels and collectives) has finished when this returns */
+int pmf_comm_barrier(pmf_ctx *ctx);
+/* element-wise sum / max of n host doubles over the ranks, result on every rank (validation sums of
+ * the sharded monitor -- hpf_cavi.py:196-211 --, timings) */
+int pmf_comm_allreduce_host(pmf_ctx *ctx, double *values, int64_t n, int op);
+/* the USER-side rows of `array` of every rank, concatenated in rank order, as host float64 on every
+ * rank; bounds[nranks + 1] = the global user ranges (what `fit` needs to hand back full
+ * E_theta / m_theta, train_poisson_full.py:68-76).  Collective. */
+int pmf_comm_gather_user_rows(pmf_ctx *ctx, int array, const int64_t *bounds, double *host_full);
+
 /* ---- Gaussian MF, MAP by stochastic gradient steps -------------
  * NO reference counterpart (the reference's Gaussian model is CAVI only): parity unpinned, the
  * oracle is this build's own restatement (oracle/cavi_oracle.py:gauss_sgd_half_sweep).  One call
@@ -277,6 +323,13 @@ int pmf_topk_items(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int k
 int pmf_prof_enable(pmf_ctx *ctx, int enable);
 int pmf_prof_reset(pmf_ctx *ctx);
 int pmf_prof_get(pmf_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
+/* Gather ceiling of the Poisson/HPF half-sweep of `side` on THIS context's ratings and tables: the
+ * average device time of `repeats` launches of the sweep kernel's memory side alone (same tasks, same
+ * index / rating streams, same 16-byte-per-lane row gathers; one add per loaded value, no row output).
+ * The gathered table of C3 (25.6 MB of item rows, 256 MB of user rows) lives in L2 / Infinity Cache,
+ * so the sweep is bound by what the caches deliver for this pattern, not by HBM: algorithmic bytes /
+ * this time is the kernel's roofline (bench.py, `roofline.bound = "cache_gather"`). */
+int pmf_prof_gather_ceiling(pmf_ctx *ctx, int side, int repeats, double *ms_per_launch);
 
 #ifdef __cplusplus
 }

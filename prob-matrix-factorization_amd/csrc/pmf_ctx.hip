@@ -231,6 +231,7 @@ extern "C" int pmf_ctx_destroy(pmf_ctx *ctx) {
     if (!ctx) return PMF_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    pmf_comm_release(ctx);
     for (auto &r : ctx->prof_pending) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -738,7 +739,7 @@ static void unpack_cov(const T *src, double *dst, int64_t rows, int K, int strid
     }
 }
 
-static void array_shape(const pmf_ctx *ctx, int array, int *host_width, int *dev_stride) {
+void pmf_array_shape(const pmf_ctx *ctx, int array, int *host_width, int *dev_stride) {
     switch (array) {
         case PMF_ARR_FACTOR:
         case PMF_ARR_SHAPE:
@@ -756,6 +757,18 @@ static void array_shape(const pmf_ctx *ctx, int array, int *host_width, int *dev
     }
 }
 
+void pmf_unpack_rows(const pmf_ctx *ctx, int array, const void *src, double *dst, int64_t rows) {
+    int width, stride;
+    pmf_array_shape(ctx, array, &width, &stride);
+    if (array == PMF_ARR_COV) {
+        if (ctx->dtype == PMF_F64) unpack_cov((const double *)src, dst, rows, ctx->K, stride);
+        else unpack_cov((const float *)src, dst, rows, ctx->K, stride);
+    } else {
+        if (ctx->dtype == PMF_F64) unpack_rows((const double *)src, dst, rows, width, stride);
+        else unpack_rows((const float *)src, dst, rows, width, stride);
+    }
+}
+
 static const int64_t kStageBytes = 64ll << 20;
 
 extern "C" int pmf_set_array(pmf_ctx *ctx, int side, int array, const double *host) {
@@ -767,7 +780,7 @@ extern "C" int pmf_set_array(pmf_ctx *ctx, int side, int array, const double *ho
     int rc = pmf_alloc_array(ctx, side, array);
     if (rc) return rc;
     int width, stride;
-    array_shape(ctx, array, &width, &stride);
+    pmf_array_shape(ctx, array, &width, &stride);
     const int64_t rows = ctx->rows[side];
     const int64_t row_bytes = (int64_t)stride * (int64_t)ctx->elem;
     const int64_t step = std::max<int64_t>(1, kStageBytes / row_bytes);
@@ -798,7 +811,7 @@ extern "C" int pmf_get_array(pmf_ctx *ctx, int side, int array, double *host) {
     int rc = pmf_require_array(ctx, side, array, "pmf_get_array");
     if (rc) return rc;
     int width, stride;
-    array_shape(ctx, array, &width, &stride);
+    pmf_array_shape(ctx, array, &width, &stride);
     const int64_t rows = ctx->rows[side];
     const int64_t row_bytes = (int64_t)stride * (int64_t)ctx->elem;
     const int64_t step = std::max<int64_t>(1, kStageBytes / row_bytes);
@@ -808,14 +821,7 @@ extern "C" int pmf_get_array(pmf_ctx *ctx, int side, int array, double *host) {
         const char *src = (const char *)ctx->arr[side][array] + r0 * row_bytes;
         PMF_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, src, (size_t)(nr * row_bytes), hipMemcpyDeviceToHost, ctx->stream));
         PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        double *dst = host + r0 * width;
-        if (array == PMF_ARR_COV) {
-            if (ctx->dtype == PMF_F64) unpack_cov((const double *)ctx->h_pinned, dst, nr, ctx->K, stride);
-            else unpack_cov((const float *)ctx->h_pinned, dst, nr, ctx->K, stride);
-        } else {
-            if (ctx->dtype == PMF_F64) unpack_rows((const double *)ctx->h_pinned, dst, nr, width, stride);
-            else unpack_rows((const float *)ctx->h_pinned, dst, nr, width, stride);
-        }
+        pmf_unpack_rows(ctx, array, ctx->h_pinned, host + r0 * width, nr);
     }
     return PMF_OK;
 }
@@ -867,26 +873,30 @@ static hipEvent_t take_event(pmf_ctx *ctx) {
     return e;
 }
 
-void pmf_prof_begin(pmf_ctx *ctx, int kernel) {
+void pmf_prof_begin_on(pmf_ctx *ctx, int kernel, hipStream_t stream) {
     if (!ctx->prof || ctx->capturing) return;
     pmf_ctx::ProfRec r;
     r.a = take_event(ctx);
     r.b = take_event(ctx);
     r.kernel = kernel;
-    (void)hipEventRecord(r.a, ctx->stream);
+    (void)hipEventRecord(r.a, stream);
     ctx->prof_pending.push_back(r);
 }
 
-void pmf_prof_end(pmf_ctx *ctx) {
+void pmf_prof_end_on(pmf_ctx *ctx, hipStream_t stream) {
     if (!ctx->prof || ctx->capturing || ctx->prof_pending.empty()) return;
-    (void)hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
+    (void)hipEventRecord(ctx->prof_pending.back().b, stream);
 }
+
+void pmf_prof_begin(pmf_ctx *ctx, int kernel) { pmf_prof_begin_on(ctx, kernel, ctx->stream); }
+void pmf_prof_end(pmf_ctx *ctx) { pmf_prof_end_on(ctx, ctx->stream); }
 
 static int prof_drain(pmf_ctx *ctx) {
     if (ctx->prof_pending.empty()) return PMF_OK;
     PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (auto &r : ctx->prof_pending) {
         float ms = 0.f;
+        PMF_HIP_CHECK(hipEventSynchronize(r.b));   // brackets on the collective stream end there
         PMF_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
         ctx->prof_ms[r.kernel] += ms;
         ctx->prof_n[r.kernel] += 1;

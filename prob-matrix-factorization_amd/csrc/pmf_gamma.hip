@@ -165,6 +165,53 @@ __global__ __launch_bounds__(256) void gamma_sweep_kernel(GammaParams<T> p) {
     }
 }
 
+// Gather ceiling of this access shape (profiling aid, pmf_prof_gather_ceiling): the sweep kernel's
+// memory side only -- the same tasks, the same coalesced index / rating loads, the same 16-byte-per-lane
+// row gathers with UN in flight -- with the arithmetic reduced to one add per loaded value and no row
+// output.  Its time is what the L2 / Infinity Cache / HBM deliver for this gather pattern; the real
+// kernel cannot be faster.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void gamma_gather_probe_kernel(GammaParams<T> p, T *sink) {
+    constexpr int G = 256 / LPR;
+    constexpr int UN = LPR < 4 ? LPR : 4;
+    const int c = threadIdx.x % LPR;
+    const int64_t task_id = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
+    if (task_id >= p.n_tasks) return;
+    const PmfTask t = p.tasks[task_id];
+    const int koff = c * PMF_VEC;
+    const bool active = koff < p.kpad;
+    const int kpad = p.kpad;
+    Vec4<T> acc = active ? load4(p.factor_self + (int64_t)t.row * kpad + koff) : zero4<T>();
+    const int32_t *col = p.other + t.start;
+    const T *val = p.val + t.start;
+    for (int base = 0; base < t.len; base += LPR) {
+        const int n = min(LPR, t.len - base);
+        int my_o = 0;
+        T my_x = (T)0;
+        if (c < n) {
+            my_o = col[base + c];
+            my_x = val[base + c];
+        }
+        acc.v[0] += my_x;
+        for (int tt = 0; tt < n; tt += UN) {
+            int o[UN];
+            Vec4<T> b[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) o[q] = __shfl(my_o, tt + q, LPR);
+#pragma unroll
+            for (int q = 0; q < UN; ++q) b[q] = active ? load4(p.factor_other + (int64_t)o[q] * kpad + koff) : zero4<T>();
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+                if (tt + q < n) {
+#pragma unroll
+                    for (int e = 0; e < PMF_VEC; ++e) acc.v[e] += b[q].v[e];
+                }
+        }
+    }
+    // never true for finite data; keeps every load alive without an output stream
+    if (acc.v[0] + acc.v[1] + acc.v[2] + acc.v[3] == (T)-1.2345678e30) sink[0] = acc.v[0];
+}
+
 // One block per split row: group g adds slots g, g+G, ... in order, the G
 // group sums are then added in group order by group 0 (fixed order => bitwise
 // reproducible), which finalises the row (or writes its raw sums in STATS mode).
@@ -247,8 +294,15 @@ __global__ __launch_bounds__(256) void gamma_finalize_all_kernel(GammaParams<T> 
 // ---------------------------------------------------------------------------
 template <typename T, int LPR>
 static int launch_gamma(pmf_ctx *ctx, int side, GammaParams<T> &p, const PmfTaskView &tl,
-                        int mode /*0 fused, 1 accumulate, 2 finalize, 3 extended*/) {
+                        int mode /*0 fused, 1 accumulate, 2 finalize, 3 extended, 4 gather probe*/) {
     constexpr int G = 256 / LPR;
+    if (mode == 4) {
+        if (tl.n_tasks > 0)
+            hipLaunchKernelGGL((gamma_gather_probe_kernel<T, LPR>), dim3((unsigned)((tl.n_tasks + G - 1) / G)), dim3(256), 0,
+                               ctx->stream, p, (T *)ctx->d_scratch);
+        PMF_HIP_CHECK(hipGetLastError());
+        return PMF_OK;
+    }
     if (mode != 2) {
         if (tl.n_tasks > 0) {
             PmfProfScope prof(ctx, PMF_KERNEL_GAMMA_SWEEP);
@@ -291,7 +345,9 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
     if ((rc = pmf_require_array(ctx, side, PMF_ARR_FACTOR, "pmf_gamma_sweep"))) return rc;
     if ((rc = pmf_require_array(ctx, other, PMF_ARR_FACTOR, "pmf_gamma_sweep"))) return rc;
     PMF_REQUIRE(ix.d_ptr, PMF_EINVAL, "pmf_gamma_sweep: ratings have not been set");
-    if (mode != 1) {
+    if (mode == 4) {
+        if ((rc = pmf_ensure_scratch(ctx, 64))) return rc;
+    } else if (mode != 1) {
         if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_SHAPE))) return rc;
         if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_RATE))) return rc;
         if (hierarchical) {
@@ -300,7 +356,7 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
         }
     }
     const int pw = 2 * ctx->kpad + (mode == 3 ? PMF_VEC : 0);
-    if (mode != 2 && tl.n_slots > 0)
+    if (mode != 2 && mode != 4 && tl.n_slots > 0)
         if ((rc = pmf_ensure_partial(ctx, (size_t)tl.n_slots * pw * sizeof(T)))) return rc;
     if (mode == 3) {
         if ((rc = pmf_require_array(ctx, side, PMF_ARR_SCALE, "pmf_gamma_ext_sweep"))) return rc;
@@ -356,9 +412,27 @@ static int run_gamma(pmf_ctx *ctx, int side, int mode, void *stats, double shape
     PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, fn ": bad side %d", side);  \
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
 
+// several ranks: accumulate -> all-reduce -> finalize on the library's statistics buffer (pmf_comm.hip)
+template <typename T>
+static int run_gamma_dist(pmf_ctx *ctx, int side, double shape_prior, double rate_prior, int hierarchical,
+                          double hyper_shape, double hyper_rate_prior) {
+    const size_t width = (size_t)2 * ctx->kpad;
+    void *stats = nullptr;
+    int rc = pmf_comm_stats(ctx, 0, (size_t)ctx->rows[side] * width * sizeof(T), &stats);
+    if (rc) return rc;
+    return pmf_comm_half_sweep(
+        ctx, side, width, stats, true, [&] { return run_gamma<T>(ctx, side, 1, stats, 0, 0, 0, 0, 0); },
+        [&] { return run_gamma<T>(ctx, side, 2, stats, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior); });
+}
+
 extern "C" int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior,
                                int hierarchical, double hyper_shape, double hyper_rate_prior) {
     GAMMA_PROLOGUE("pmf_gamma_sweep");
+    if (side == PMF_SIDE_ITEM && pmf_comm_active(ctx)) {
+        if (ctx->dtype == PMF_F64)
+            return run_gamma_dist<double>(ctx, side, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+        return run_gamma_dist<float>(ctx, side, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+    }
     if (ctx->dtype == PMF_F64)
         return run_gamma<double>(ctx, side, 0, nullptr, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
     return run_gamma<float>(ctx, side, 0, nullptr, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
@@ -366,6 +440,7 @@ extern "C" int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, doubl
 
 extern "C" int pmf_gamma_ext_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior) {
     GAMMA_PROLOGUE("pmf_gamma_ext_sweep");
+    PMF_REQUIRE(!pmf_comm_active(ctx), PMF_EINVAL, "pmf_gamma_ext_sweep: the extended model is not available on several ranks");
     if (ctx->dtype == PMF_F64) return run_gamma<double>(ctx, side, 3, nullptr, shape_prior, rate_prior, 0, 0, 0);
     return run_gamma<float>(ctx, side, 3, nullptr, shape_prior, rate_prior, 0, 0, 0);
 }
@@ -385,4 +460,41 @@ extern "C" int pmf_gamma_finalize(pmf_ctx *ctx, int side, const void *stats_dev,
     if (ctx->dtype == PMF_F64)
         return run_gamma<double>(ctx, side, 2, (void *)stats_dev, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
     return run_gamma<float>(ctx, side, 2, (void *)stats_dev, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior);
+}
+
+// Profiling aid (no reference counterpart): average device time of `repeats` launches of the
+// gather-only twin of the Poisson/HPF half-sweep of `side` -- the ceiling the cache hierarchy sets
+// for this context's gather pattern (bench.py reports the sweep kernel against it).
+extern "C" int pmf_prof_gather_ceiling(pmf_ctx *ctx, int side, int repeats, double *ms_per_launch) {
+    GAMMA_PROLOGUE("pmf_prof_gather_ceiling");
+    PMF_REQUIRE(ms_per_launch != nullptr && repeats >= 1, PMF_EINVAL, "pmf_prof_gather_ceiling: bad arguments");
+    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "pmf_prof_gather_ceiling: a capture is open");
+    hipEvent_t a = nullptr, b = nullptr;
+    PMF_HIP_CHECK(hipEventCreate(&a));
+    hipError_t e = hipEventCreate(&b);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(a);
+        pmf_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+        return PMF_EHIP;
+    }
+    int rc = PMF_OK;
+    for (int k = 0; k <= repeats && !rc; ++k) {   // launch 0 warms the caches and is not timed
+        if (k == 1) (void)hipEventRecord(a, ctx->stream);
+        rc = ctx->dtype == PMF_F64 ? run_gamma<double>(ctx, side, 4, nullptr, 0, 0, 0, 0, 0)
+                                   : run_gamma<float>(ctx, side, 4, nullptr, 0, 0, 0, 0, 0);
+    }
+    float ms = 0.f;
+    if (!rc) {
+        e = hipEventRecord(b, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e != hipSuccess) {
+            pmf_set_error("pmf_prof_gather_ceiling: %s", hipGetErrorString(e));
+            rc = PMF_EHIP;
+        }
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_per_launch = (double)ms / repeats;
+    return rc;
 }

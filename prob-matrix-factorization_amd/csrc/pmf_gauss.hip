@@ -1260,9 +1260,28 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     return PMF_OK;
 }
 
+// several ranks: accumulate -> all-reduce -> finalize on the library's statistics buffer (pmf_comm.hip)
+template <typename T>
+static int run_factor_dist(pmf_ctx *ctx, int side, double sigma2, double eta2) {
+    const size_t width = (size_t)ctx->cov_stride + ctx->kpad;
+    void *stats = nullptr;
+    int rc = pmf_comm_stats(ctx, 0, (size_t)ctx->rows[side] * width * sizeof(T), &stats);
+    if (rc) return rc;
+    return pmf_comm_half_sweep(
+        ctx, side, width, stats, true,
+        [&] {
+            bool fused = false;
+            return run_factor_accumulate<T>(ctx, side, stats, 1.0, 1.0, &fused);
+        },
+        [&] { return run_factor_solve<T>(ctx, side, stats, sigma2, eta2); });
+}
+
 extern "C" int pmf_gauss_factor_sweep(pmf_ctx *ctx, int side, double sigma2, double eta2) {
     GAUSS_PROLOGUE("pmf_gauss_factor_sweep");
     PMF_REQUIRE(sigma2 > 0 && eta2 > 0, PMF_EINVAL, "pmf_gauss_factor_sweep: variances must be positive");
+    if (side == PMF_SIDE_ITEM && pmf_comm_active(ctx))
+        return ctx->dtype == PMF_F64 ? run_factor_dist<double>(ctx, side, sigma2, eta2)
+                                     : run_factor_dist<float>(ctx, side, sigma2, eta2);
     int rc;
     bool fused = false;
     if (ctx->dtype == PMF_F64) {
@@ -1363,8 +1382,21 @@ static int run_bias(pmf_ctx *ctx, int side, int mode, void *stats, double sigma2
     return PMF_OK;
 }
 
+template <typename T>
+static int run_bias_dist(pmf_ctx *ctx, int side, double sigma2, double eta_bias2) {
+    void *stats = nullptr;   // [rows x 2]: latency-bound, one message
+    int rc = pmf_comm_stats(ctx, 1, (size_t)ctx->rows[side] * 2 * sizeof(T), &stats);
+    if (rc) return rc;
+    return pmf_comm_half_sweep(
+        ctx, side, 2, stats, false, [&] { return run_bias<T>(ctx, side, 1, stats, 1, 1); },
+        [&] { return run_bias<T>(ctx, side, 2, stats, sigma2, eta_bias2); });
+}
+
 extern "C" int pmf_gauss_bias_sweep(pmf_ctx *ctx, int side, double sigma2, double eta_bias2) {
     GAUSS_PROLOGUE("pmf_gauss_bias_sweep");
+    if (side == PMF_SIDE_ITEM && pmf_comm_active(ctx))
+        return ctx->dtype == PMF_F64 ? run_bias_dist<double>(ctx, side, sigma2, eta_bias2)
+                                     : run_bias_dist<float>(ctx, side, sigma2, eta_bias2);
     if (ctx->dtype == PMF_F64) return run_bias<double>(ctx, side, 0, nullptr, sigma2, eta_bias2);
     return run_bias<float>(ctx, side, 0, nullptr, sigma2, eta_bias2);
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -133,6 +134,13 @@ struct pmf_ctx {
 
     int64_t device_bytes = 0;
 
+    // multi-GPU (pmf_comm.hip): the communicator (shared between contexts of one process, refcounted)
+    // and the library-owned statistics buffers of the item half-sweeps
+    // (0: factor / gamma / gradient statistics, 1: Gaussian bias statistics)
+    struct PmfComm *comm = nullptr;
+    void *d_stats[2] = {nullptr, nullptr};
+    size_t stats_bytes[2] = {0, 0};
+
     // HIP graphs captured from sequences of sweep calls (pmf_graph_begin / _end)
     bool capturing = false;
     std::vector<hipGraphExec_t> graphs;
@@ -174,9 +182,23 @@ int pmf_index_device_begin(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids, c
 void pmf_index_device_abort(PmfIndexBuild *b);
 int pmf_index_device_finish(pmf_ctx *ctx, PmfIndexBuild *b, int64_t nnz);
 
-// profiling brackets
+// host <-> device layout helpers (pmf_ctx.hip)
+void pmf_array_shape(const pmf_ctx *ctx, int array, int *host_width, int *dev_stride);
+void pmf_unpack_rows(const pmf_ctx *ctx, int array, const void *src, double *dst, int64_t rows);
+
+// multi-GPU (pmf_comm.hip).  With an attached communicator of more than one rank the ITEM half-sweeps
+// run  accumulate -> all-reduce -> finalize  through pmf_comm_half_sweep.
+bool pmf_comm_active(const pmf_ctx *ctx);
+void pmf_comm_release(pmf_ctx *ctx);   // detach + free the statistics buffers (pmf_ctx_destroy)
+int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out);
+int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool chunked,
+                        const std::function<int()> &accumulate, const std::function<int()> &finalize);
+
+// profiling brackets (the *_on forms time work on another stream than the context's)
 void pmf_prof_begin(pmf_ctx *ctx, int kernel);
 void pmf_prof_end(pmf_ctx *ctx);
+void pmf_prof_begin_on(pmf_ctx *ctx, int kernel, hipStream_t stream);
+void pmf_prof_end_on(pmf_ctx *ctx, hipStream_t stream);
 
 struct PmfProfScope {
     pmf_ctx *ctx;

@@ -264,6 +264,17 @@ extern "C" int pmf_gauss_sgd_finalize(pmf_ctx *ctx, int side, const void *stats_
 
 extern "C" int pmf_gauss_sgd_sweep(pmf_ctx *ctx, int side, double lr, double sigma2, double eta2, double eta_bias2) {
     SGD_PROLOGUE("pmf_gauss_sgd_sweep");
+    if (side == PMF_SIDE_ITEM && pmf_comm_active(ctx)) {
+        // several ranks: the items' rating-count-weighted displacement sums are all-reduced (pmf_comm.hip)
+        const size_t width = (size_t)ctx->kpad + PMF_VEC;
+        void *stats = nullptr;
+        int rc = pmf_comm_stats(ctx, 0, (size_t)ctx->rows[side] * width * ctx->elem, &stats);
+        if (rc) return rc;
+        return pmf_comm_half_sweep(
+            ctx, side, width, stats, true,
+            [&] { return pmf_gauss_sgd_accumulate(ctx, side, stats, lr, sigma2, eta2, eta_bias2); },
+            [&] { return pmf_gauss_sgd_finalize(ctx, side, stats); });
+    }
     const int saved = ctx->cur_chunk[side];
     ctx->cur_chunk[side] = -1;  // the one-call form always covers every row
     const size_t bytes = (size_t)ctx->rows[side] * (ctx->kpad + PMF_VEC) * ctx->elem;

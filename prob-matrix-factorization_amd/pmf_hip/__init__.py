@@ -21,7 +21,10 @@ USER, ITEM = 0, 1
  ARR_SCALE_RATE) = range(10)
 PREDICT_BIAS, PREDICT_SCALE = 1, 2
 KERNEL_NAMES = ("gamma_sweep", "gamma_final", "gauss_accum", "gauss_solve", "gauss_bias",
-                "eval", "predict", "topk", "gauss_combine", "gauss_sgd")
+                "eval", "predict", "topk", "gauss_combine", "gauss_sgd", "comm_allreduce", "comm_wait")
+UNIQUE_ID_BYTES = 128
+TRANSPORT_RCCL, TRANSPORT_HOSTSHM = 0, 1
+OP_SUM, OP_MAX = 0, 1
 MAX_LABELS = 32
 
 
@@ -83,9 +86,26 @@ SIGNATURES = {
     "pmf_prof_enable": (C.c_int, [_p, C.c_int]),
     "pmf_prof_reset": (C.c_int, [_p]),
     "pmf_prof_get": (C.c_int, [_p, C.c_int, _f64p, _i64p]),
+    "pmf_prof_gather_ceiling": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
+    "pmf_comm_unique_id": (C.c_int, [_p]),
+    "pmf_comm_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
+    "pmf_comm_init_hostshm": (C.c_int, [_p, C.c_int, C.c_int, _p]),
+    "pmf_comm_attach": (C.c_int, [_p, _p]),
+    "pmf_comm_destroy": (C.c_int, [_p]),
+    "pmf_comm_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pmf_comm_barrier": (C.c_int, [_p]),
+    "pmf_comm_allreduce_host": (C.c_int, [_p, _f64p, C.c_int64, C.c_int]),
+    "pmf_comm_gather_user_rows": (C.c_int, [_p, C.c_int, _i64p, _f64p]),
 }
 
 _lib = None
+_loaded_before_torch = False
+
+
+def loaded_before_torch():
+    """True when libpmf_hip.so (and with it /opt/rocm's HIP runtime) was mapped into a process that
+    had not imported torch yet: a later `import torch` would then find no GPU."""
+    return _lib is not None and _loaded_before_torch
 
 
 def load():
@@ -98,12 +118,18 @@ def load():
             f"{LIB_PATH} not found: the HIP engine has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` from the repository root. "
             "There is no CPU fallback.")
-    # PyTorch-ROCm wheels bundle their own HIP runtime.  If /opt/rocm's libamdhip64 (this
-    # library's dependency) is mapped first, a later `import torch` ends up with two runtimes and
-    # silently reports no GPU.  Loading torch first makes both share torch's copy.
-    if "torch" not in sys.modules and os.environ.get("PMF_HIP_NO_TORCH_PRELOAD") != "1":
+    # The CAVI engine does not use PyTorch.  One interaction has to be known, though: PyTorch-ROCm
+    # wheels bundle their own HIP runtime, and if /opt/rocm's libamdhip64 (this library's dependency)
+    # is mapped first, a later `import torch` ends up with two runtimes and silently reports no GPU.
+    # A process that ALSO wants torch on the GPU (the hpf_pytorch model, the comparison drivers)
+    # must therefore import torch before the first engine call -- src/models/hpf_pytorch.py and the
+    # drivers do so at import time; PMF_HIP_TORCH_PRELOAD=1 forces it here.
+    global _loaded_before_torch
+    _loaded_before_torch = "torch" not in sys.modules
+    if _loaded_before_torch and os.environ.get("PMF_HIP_TORCH_PRELOAD") == "1":
         try:
             import torch  # noqa: F401
+            _loaded_before_torch = False
         except Exception:
             pass
     try:

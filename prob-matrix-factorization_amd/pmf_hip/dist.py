@@ -1,51 +1,40 @@
-"""Multi-GPU orchestration of one CAVI iteration.
+"""Multi-GPU runs of the CAVI engine -- no PyTorch anywhere on this path.
 
-Ratings are sharded by USER RANGE: rank g owns a contiguous block of users,
-all of their ratings and their theta-side state; the item-side state is
-replicated.  The user half-sweeps are purely local.  An item half-sweep is
+Ratings are sharded by USER RANGE: rank g (one process per GPU) owns a contiguous block of users,
+all of their ratings and their theta-side state; the item-side state is replicated.  The user
+half-sweeps are purely local.  An item half-sweep is
 
-    local raw sums over this rank's ratings  ->  all-reduce (RCCL)  ->  finalise
+    local raw sums over this rank's ratings  ->  all-reduce  ->  finalise
 
-so every rank ends each iteration with identical item factors.  The exchanged
-quantity is the per-item sufficient statistic, not a gradient: [I x 2Kpad] for
-Poisson/HPF, [I x (Kp + Kpad)] (packed normal matrix + right-hand side) and
-[I x 2] (bias) for the Gaussian model.
+so every rank ends each iteration with identical item factors.  The exchanged quantity is the
+per-item sufficient statistic, not a gradient: [I x 2Kpad] for Poisson/HPF, [I x (Kp + Kpad)]
+(packed normal matrix + right-hand side) and [I x 2] (bias) for the Gaussian model.
 
-The functions here only sequence engine calls and collectives.  `engine` is any
-object with the `Context` half-sweep methods (pmf_hip.Context on a GPU; the CPU
-tests drive the same code with an oracle-backed stand-in over gloo), `comm` is
-a `Comm` (or None for a single process).
+Where the collective runs:
+
+* `Comm` (this module): the communicator lives INSIDE libpmf_hip.so (`pmf_comm_init`: RCCL over xGMI,
+  second HIP stream, event ordering, library-owned statistics buffers, chunk pipelining).  A context
+  that `Comm.attach`ed simply calls `gamma_sweep(ITEM, ...)` etc.; the library does the three stages.
+  `init_from_env()` builds one from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+  MASTER_PORT as set by `python -m torch.distributed.run` or any other launcher) and exchanges the
+  RCCL unique id through a file.
+* an external collective (anything with `all_reduce(stats)` / `all_reduce_async(stats)` and
+  `in_library = False`): the host sequences `*_accumulate` -> collective -> `*_finalize` on a
+  caller-owned statistics buffer (`_item_half_sweep`).  That is the bring-your-own-communicator form
+  of the C-ABI; the CPU tests drive it over gloo with an oracle-backed engine.
 """
 from __future__ import annotations
 
+import os
+import tempfile
+import time
+
 import numpy as np
 
-from . import ITEM, USER
+from . import ITEM, UNIQUE_ID_BYTES, USER
 
 
-class Comm:
-    """torch.distributed wrapper: backend 'nccl' (= RCCL on ROCm) for device
-    tensors, 'gloo' for the CPU tests."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-
-    def all_reduce(self, tensor):
-        self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
-        return tensor
-
-    def all_reduce_async(self, tensor):
-        """Returns the work handle; `.wait()` orders the current stream after the collective."""
-        return self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-    def barrier(self):
-        self._dist.barrier(group=self.group)
-
-
+# ---- sharding -----------------------------------------------------------------
 def shard_bounds(user_ids, n_users, world):
     """User-range boundaries [b_0 = 0, ..., b_world = n_users] balanced by the
     number of ratings per shard, not by the number of users.  Every range holds at
@@ -74,13 +63,124 @@ def take_shard(user_ids, item_ids, ratings, bounds, rank):
     return u[sel] - lo, np.asarray(item_ids)[sel], np.asarray(ratings)[sel]
 
 
-# ---- one iteration per model ------------------------------------------------
+# ---- the in-library communicator -------------------------------------------------
+class Comm:
+    """This process's communicator inside libpmf_hip.so (one rank per GPU).
+
+    A tiny anchor context owns it; model / bench contexts share it with `attach(ctx)`, after
+    which their ITEM half-sweeps are distributed by the library itself."""
+
+    in_library = True
+
+    def __init__(self, rank, world, device, unique_id, transport="rccl"):
+        from .engine import Context
+        self.rank, self.world, self.device, self.transport = int(rank), int(world), int(device), transport
+        self._anchor = Context(1, 1, 1, dtype="f32", device=self.device)
+        try:
+            self._anchor.comm_init(self.world, self.rank, unique_id, transport)
+        except Exception:
+            self._anchor.close()
+            raise
+
+    def attach(self, ctx):
+        ctx.comm_attach(self._anchor)
+        return ctx
+
+    def all_reduce_host(self, values, op="sum"):
+        """Element-wise sum / max of a small host array over the ranks (validation sums, timings)."""
+        return self._anchor.comm_allreduce_host(values, op)
+
+    def barrier(self):
+        self._anchor.comm_barrier()
+
+    def close(self):
+        if self._anchor is not None:
+            self._anchor.close()
+            self._anchor = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+_exchange_seq = 0
+
+
+def _id_file(tag):
+    explicit = os.environ.get("PMF_COMM_ID_FILE")
+    if explicit:
+        return f"{explicit}.{tag}"
+    base = os.environ.get("PMF_COMM_DIR", tempfile.gettempdir())
+    # all ranks of one launch are children of one launcher process (torch.distributed.run's agent,
+    # mp.spawn, a shell): its pid + the rendezvous port name the launch
+    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    return os.path.join(base, f"pmf_hip_uid_{key}.{tag}")
+
+
+def exchange_unique_id(rank, make_id, timeout=180.0):
+    """Rank 0 creates the 128-byte id and publishes it in a file (written whole, then renamed);
+    the other ranks wait for the file.  Called by every rank, the same number of times."""
+    global _exchange_seq
+    path = _id_file(_exchange_seq)
+    _exchange_seq += 1
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == UNIQUE_ID_BYTES:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
+def init_from_env(device=None, transport=None):
+    """The communicator of a launcher-started process, or None for a single process.
+
+    Reads RANK, WORLD_SIZE, LOCAL_RANK (the GPU of this rank unless `device` is given).  `transport`:
+    'rccl' (default; PMF_COMM_TRANSPORT overrides) or 'hostshm' for ranks that share one GPU."""
+    from .engine import Context
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    rank = int(os.environ.get("RANK", "0"))
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    transport = transport or os.environ.get("PMF_COMM_TRANSPORT", "rccl")
+    uid, path = exchange_unique_id(rank, Context.comm_unique_id)
+    comm = Comm(rank, world, device, uid, transport)
+    comm.barrier()            # every rank has read the file
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return comm
+
+
+def distributed(comm):
+    return comm is not None and comm.world > 1
+
+
+# ---- one iteration per model -------------------------------------------------------
 def _item_half_sweep(engine, comm, stats, width, accumulate, finalize):
-    """accumulate -> all-reduce -> finalize over the item rows.  When the engine has item row
-    chunks (`set_row_chunks(ITEM, n)`, the same n on every rank) the three stages are pipelined:
-    the statistics of chunk c travel (asynchronous all-reduce on the collective's own stream)
-    while chunk c+1 is accumulated, and chunk c is finalised while later chunks still travel.
-    The arithmetic per row is that of the unchunked call, so results do not depend on n."""
+    """External-collective form: accumulate -> all-reduce -> finalize over the item rows, sequenced
+    by the host on a caller-owned statistics buffer.  With item row chunks (`set_row_chunks(ITEM, n)`,
+    the same n on every rank) the three stages are pipelined: the statistics of chunk c travel
+    (asynchronous all-reduce) while chunk c+1 is accumulated, and chunk c is finalised while later
+    chunks still travel.  The arithmetic per row is that of the unchunked call."""
     n = getattr(engine, "n_chunks", {}).get(ITEM, 1)
     if n <= 1:
         accumulate()
@@ -102,12 +202,18 @@ def _item_half_sweep(engine, comm, stats, width, accumulate, finalize):
         engine.select_chunk(ITEM, -1)
 
 
+def _fused_item(comm):
+    """The engine's one-call ITEM sweep is the whole distributed half-sweep: single process, or the
+    communicator lives in the library."""
+    return (not distributed(comm)) or getattr(comm, "in_library", False)
+
+
 def gamma_iteration(engine, comm, stats_item, user_prior, item_prior):
     """Poisson MF / HPF.  `*_prior` = (shape_prior, rate_prior, hierarchical,
-    hyper_shape, hyper_rate_prior) as taken by `gamma_sweep`.
-    `stats_item` is the [I x 2 x Kpad] buffer object with `.ptr` and `.tensor`."""
+    hyper_shape, hyper_rate_prior) as taken by `gamma_sweep`.  `stats_item` is only used with an
+    external collective: the [I x 2 x Kpad] buffer object with `.ptr` and `.tensor`."""
     engine.gamma_sweep(USER, *user_prior)
-    if comm is None or comm.world == 1:
+    if _fused_item(comm):
         engine.gamma_sweep(ITEM, *item_prior)
         return
     _item_half_sweep(engine, comm, stats_item, 2 * engine.kpad,
@@ -119,9 +225,9 @@ def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2,
                        eta_bias2=None):
     """Gaussian MF (+ biases when eta_bias2 is given), order as
     gaussian_mf_cavi_bias.py:129-263."""
-    single = comm is None or comm.world == 1
+    fused = _fused_item(comm)
     engine.gauss_factor_sweep(USER, sigma2, eta_theta2)
-    if single:
+    if fused:
         engine.gauss_factor_sweep(ITEM, sigma2, eta_beta2)
     else:
         _item_half_sweep(engine, comm, stats_item, engine.cov_stride + engine.kpad,
@@ -130,7 +236,7 @@ def gaussian_iteration(engine, comm, stats_item, stats_bias, sigma2, eta_theta2,
     if eta_bias2 is None:
         return
     engine.gauss_bias_sweep(USER, sigma2, eta_bias2)
-    if single:
+    if fused:
         engine.gauss_bias_sweep(ITEM, sigma2, eta_bias2)
     else:
         # [I x 2]: latency-bound, one message (chunk selection is -1 = all rows here)
@@ -143,7 +249,7 @@ def gaussian_sgd_iteration(engine, comm, stats_item, lr, sigma2, eta_theta2, eta
     """One epoch of the MAP / gradient mode (no reference counterpart): users, then items; on
     several ranks the items' rating-count-weighted displacement sums are all-reduced."""
     engine.gauss_sgd_sweep(USER, lr, sigma2, eta_theta2, eta_bias2)
-    if comm is None or comm.world == 1:
+    if _fused_item(comm):
         engine.gauss_sgd_sweep(ITEM, lr, sigma2, eta_beta2, eta_bias2)
         return
     _item_half_sweep(engine, comm, stats_item, engine.sgd_stats_width,
@@ -151,58 +257,10 @@ def gaussian_sgd_iteration(engine, comm, stats_item, lr, sigma2, eta_theta2, eta
                      lambda: engine.gauss_sgd_finalize(ITEM, stats_item.ptr))
 
 
-class StreamScope:
-    """Puts one engine context and torch (its allocator, its collectives) on the SAME
-    non-default HIP stream, so that kernels, all-reduces and copies are ordered without
-    host synchronisation.  (torch's default stream has the null handle, which
-    `pmf_ctx_set_stream` would read as "use the context's own stream".)
-
-        scope = StreamScope(ctx, device); scope.enter()   ...   scope.exit()
-    """
-
-    def __init__(self, ctx, device):
-        import torch
-        self._torch = torch
-        self.stream = torch.cuda.Stream(device=device)
-        self._ctx = ctx
-        self._cm = None
-
-    def enter(self):
-        assert self.stream.cuda_stream != 0
-        self._ctx.set_stream(self.stream.cuda_stream)
-        self._cm = self._torch.cuda.stream(self.stream)
-        self._cm.__enter__()
-        return self
-
-    def exit(self):
-        if self._cm is not None:
-            self.stream.synchronize()
-            self._cm.__exit__(None, None, None)
-            self._cm = None
-            self._ctx.set_stream(None)
-
-    __enter__ = enter
-
-    def __exit__(self, *exc):
-        self.exit()
-
-
-class DeviceStats:
-    """A device buffer owned by torch (so RCCL can all-reduce it) whose raw
-    pointer is handed to the C-ABI accumulate / finalize calls."""
-
-    def __init__(self, n_elems, np_dtype, device):
-        import torch
-        tdt = torch.float64 if np_dtype == np.float64 else torch.float32
-        self.tensor = torch.zeros(int(n_elems), dtype=tdt, device=device)
-        self.ptr = self.tensor.data_ptr()
-
-
 def default_item_chunks(world, message_bytes=0):
     """Item row chunks of a sharded run.  PMF_DIST_CHUNKS if set; else slices of about 256 MB,
     at least 4 (so that at most a quarter of the all-reduce is exposed) and at most 32, but never
     below 4 MB per slice (latency-bound collectives).  1 = no pipelining."""
-    import os
     if world <= 1:
         return 1
     if "PMF_DIST_CHUNKS" in os.environ:
@@ -215,16 +273,3 @@ def item_message_bytes(ctx, gaussian):
     """Bytes of the item statistics one iteration all-reduces (the factor half-sweep's message)."""
     width = (ctx.cov_stride + ctx.kpad) if gaussian else 2 * ctx.kpad
     return ctx.n_items * width * np.dtype(ctx.np_dtype).itemsize
-
-
-def gamma_stats(ctx, device):
-    return DeviceStats(ctx.n_items * 2 * ctx.kpad, ctx.np_dtype, device)
-
-
-def sgd_stats(ctx, device):
-    return DeviceStats(ctx.n_items * ctx.sgd_stats_width, ctx.np_dtype, device)
-
-
-def gauss_stats(ctx, device):
-    return (DeviceStats(ctx.n_items * (ctx.cov_stride + ctx.kpad), ctx.np_dtype, device),
-            DeviceStats(ctx.n_items * 2, ctx.np_dtype, device))

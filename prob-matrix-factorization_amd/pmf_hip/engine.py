@@ -10,8 +10,8 @@ import ctypes as C
 
 import numpy as np
 
-from . import (ARR_COV, F32, F64, ITEM, KERNEL_NAMES, MAX_LABELS, USER, PmfError, as_f64, as_i32,
-               check, load, ptr)
+from . import (ARR_COV, F32, F64, ITEM, KERNEL_NAMES, MAX_LABELS, OP_MAX, OP_SUM, UNIQUE_ID_BYTES, USER, PmfError,
+               as_f64, as_i32, check, load, ptr)
 
 
 class Context:
@@ -53,6 +53,52 @@ class Context:
 
     def select_chunk(self, side, chunk):
         check(self._lib.pmf_ctx_select_chunk(self._h, side, int(chunk)), "pmf_ctx_select_chunk")
+
+    # ---- multi-GPU: the communicator lives inside the library -------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0 creates them, every rank passes them to comm_init)."""
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        check(load().pmf_comm_unique_id(buf), "pmf_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id, transport="rccl"):
+        """Collective.  transport 'rccl' (one rank per GPU) or 'hostshm' (rehearsal: ranks share one GPU)."""
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError(f"unique_id must be {UNIQUE_ID_BYTES} bytes")
+        fn = {"rccl": self._lib.pmf_comm_init, "hostshm": self._lib.pmf_comm_init_hostshm}[transport]
+        check(fn(self._h, int(nranks), int(rank), C.c_char_p(bytes(unique_id))), f"pmf_comm_init[{transport}]")
+
+    def comm_attach(self, owner):
+        check(self._lib.pmf_comm_attach(self._h, owner._h), "pmf_comm_attach")
+
+    def comm_destroy(self):
+        check(self._lib.pmf_comm_destroy(self._h), "pmf_comm_destroy")
+
+    def comm_info(self):
+        """(nranks, rank, transport id or -1 without a communicator)"""
+        n, r, t = C.c_int(1), C.c_int(0), C.c_int(-1)
+        check(self._lib.pmf_comm_info(self._h, C.byref(n), C.byref(r), C.byref(t)), "pmf_comm_info")
+        return n.value, r.value, t.value
+
+    def comm_barrier(self):
+        check(self._lib.pmf_comm_barrier(self._h), "pmf_comm_barrier")
+
+    def comm_allreduce_host(self, values, op="sum"):
+        a = np.array(values, dtype=np.float64, copy=True).reshape(-1)
+        check(self._lib.pmf_comm_allreduce_host(self._h, ptr(a, C.c_double), a.size, OP_MAX if op == "max" else OP_SUM),
+              "pmf_comm_allreduce_host")
+        return a.reshape(np.shape(values))
+
+    def gather_user_rows(self, array, bounds):
+        """Every rank's USER rows of `array`, concatenated in rank order (host float64, on every rank)."""
+        b = np.ascontiguousarray(np.asarray(bounds, dtype=np.int64))
+        total = int(b[-1])
+        shape = {2: (total, self.K), 3: (total, self.K, self.K)}.get(len(self._host_shape(USER, array)), (total,))
+        out = np.empty(shape, dtype=np.float64)
+        check(self._lib.pmf_comm_gather_user_rows(self._h, int(array), ptr(b, C.c_int64), ptr(out, C.c_double)),
+              "pmf_comm_gather_user_rows")
+        return out
 
     # ---- lifetime -------------------------------------------------------
     def close(self):
@@ -260,6 +306,12 @@ class Context:
 
     def prof_reset(self):
         check(self._lib.pmf_prof_reset(self._h), "pmf_prof_reset")
+
+    def gather_ceiling_ms(self, side, repeats=5):
+        """Average ms of the gather-only twin of the Poisson/HPF half-sweep of `side` (its roofline)."""
+        ms = C.c_double(0.0)
+        check(self._lib.pmf_prof_gather_ceiling(self._h, side, int(repeats), C.byref(ms)), "pmf_prof_gather_ceiling")
+        return ms.value
 
     def prof_get(self):
         """{kernel_name: (total_ms, launches)} since the last reset."""

@@ -11,6 +11,7 @@ import traceback
 from dataclasses import asdict
 
 import numpy as np
+import torch  # before the first engine call: pmf_hip.load() explains the load order (reference: compare_models.py:20 imports it at the top too)
 import pandas as pd
 
 from src.data.load_data import load_all_splits
@@ -136,7 +137,6 @@ def run_hpf_cavi(train_df, val_df, test_df, config_dict=None, verbose=False):
 
 
 def run_hpf_pytorch(train_df, val_df, test_df, config_dict=None, verbose=False):
-    import torch
     from src.experiments._full_training import row_counts
     from src.experiments.train_hpf_pytorch_full import adam_epochs, pick_device
     from src.models.hpf_pytorch import HPF_PyTorch, HPF_PyTorch_Config

@@ -13,6 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 from dataclasses import asdict
 
 import numpy as np
+import torch  # before the first engine call: pmf_hip.load() explains the load order (reference: compare_models.py:20 imports it at the top too)
 
 from src.data.load_data import load_all_splits
 from src.evaluation.metrics import macro_mae, rmse
@@ -129,7 +130,6 @@ def tune_hpf_cavi(train_df, val_df, n_trials=10, verbose=False):
 
 
 def tune_hpf_pytorch(train_df, val_df, n_trials=10, verbose=False):
-    import torch
     from src.experiments._full_training import row_counts
     from src.experiments.train_hpf_pytorch_full import adam_epochs, pick_device
     from src.models.hpf_pytorch import HPF_PyTorch, HPF_PyTorch_Config

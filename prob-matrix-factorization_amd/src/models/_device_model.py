@@ -41,10 +41,11 @@ class DeviceModel:
     _gaussian = False     # Gaussian models exchange [I x (Kp + Kpad)] statistics, the others [I x 2 Kpad]
 
     def __init__(self, config, dtype=None, device=None, comm=None):
-        """`comm`: a `pmf_hip.dist.Comm` (torch.distributed group, one rank per GPU) makes
-        `fit` a user-sharded multi-GPU run: every rank passes the SAME frames, keeps the
-        ratings of its user range, item statistics are all-reduced once per item
-        half-sweep, and every rank ends with the full factor matrices."""
+        """`comm`: a `pmf_hip.dist.Comm` (the RCCL communicator inside libpmf_hip.so, one rank
+        per GPU; `pmf_hip.dist.init_from_env()`) makes `fit` a user-sharded multi-GPU run: every
+        rank passes the SAME frames, keeps the ratings of its user range, item statistics are
+        all-reduced once per item half-sweep by the library, and every rank ends with the full
+        factor matrices."""
         self.config = config
         self._comm = comm if (comm is not None and comm.world > 1) else None
         self._bounds = None
@@ -54,7 +55,6 @@ class DeviceModel:
         self._device = engine_device(device)
         self._ctx = None
         self._shard_ctx = None
-        self._scope = None
         self._graph = None
         self._graph_calls = 0
         # structured per-iteration record next to the reference's stdout lines
@@ -73,19 +73,17 @@ class DeviceModel:
         if self._ctx is not None:
             self._ctx.close()
         n_local = self.n_users
+        from pmf_hip import dist as pdist
         if self._comm is not None:
-            from pmf_hip import dist as pdist
             self._bounds = pdist.shard_bounds(u, self.n_users, self._comm.world)
             u, i, x = pdist.take_shard(u, i, x, self._bounds, self._comm.rank)
             n_local = int(self._bounds[self._comm.rank + 1] - self._bounds[self._comm.rank])
         self._ctx = pmf_hip.Context(n_local, self.n_items, self.config.n_factors,
                                     dtype=self._dtype, device=self._device)
         if self._comm is not None:
-            import torch
-            from pmf_hip import dist as pdist
-            torch.cuda.set_device(self._device)
-            self._exit_stream()
-            self._scope = pdist.StreamScope(self._ctx, self._device_obj()).enter()
+            # from here on the library runs this context's ITEM half-sweeps as
+            # accumulate -> all-reduce -> finalize, pipelined over the item row chunks
+            self._comm.attach(self._ctx)
             self._ctx.set_row_chunks(pmf_hip.ITEM, pdist.default_item_chunks(
                 self._comm.world, pdist.item_message_bytes(self._ctx, self._gaussian)))
         self._ctx.set_ratings(u, i, x)
@@ -125,43 +123,24 @@ class DeviceModel:
         lo, hi = int(self._bounds[self._comm.rank]), int(self._bounds[self._comm.rank + 1])
         return full_user_array[lo:hi]
 
-    def _gather_users(self, local):
-        """All ranks' user-side rows, concatenated in user order, on every rank."""
+    def _user_array(self, array_id, ctx=None):
+        """A user-side state array for ALL users on the host: this context's rows, or -- after a
+        sharded fit -- every rank's rows in user order (a collective: every rank must call it)."""
+        ctx = ctx or self._ctx
         if self._comm is None:
-            return local
-        import torch
-        sizes = np.diff(self._bounds).astype(int)
-        width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
-        pad = np.zeros((int(sizes.max()), width))
-        pad[:len(local)] = local.reshape(len(local), width)
-        dev = torch.device("cuda", self._device)
-        mine = torch.from_numpy(pad).to(dev)
-        parts = [torch.empty_like(mine) for _ in range(self._comm.world)]
-        self._comm._dist.all_gather(parts, mine, group=self._comm.group)
-        rows = [p.cpu().numpy()[:n] for p, n in zip(parts, sizes)]
-        return np.concatenate(rows, axis=0).reshape((-1,) + local.shape[1:])
-
-    def _exit_stream(self):
-        scope = getattr(self, "_scope", None)
-        if scope is not None:
-            scope.exit()
-            self._scope = None
+            return ctx.get_array(USER, array_id)
+        return ctx.gather_user_rows(array_id, self._bounds)
 
     def _finish_sharded(self, arrays):
         """After a sharded fit every rank holds the full factors on the host; give it a
         full-size context too, so predict / evaluate / top-k work as after a single-GPU fit.
         `arrays`: [(side, array_id, host_array)].  The training shard stays in `_shard_ctx`."""
-        self._exit_stream()
         self._shard_ctx = self._ctx
         full = pmf_hip.Context(self.n_users, self.n_items, self.config.n_factors, dtype=self._dtype,
                                device=self._device)
         for side, array_id, host in arrays:
             full.set_array(side, array_id, host)
         self._ctx = full
-
-    def _device_obj(self):
-        import torch
-        return torch.device("cuda", self._device)
 
     def _need_ctx(self):
         if self._ctx is None:
@@ -212,7 +191,6 @@ class DeviceModel:
         """Every rank scores the validation pairs of its own users (pairs with an unseen
         user go to the last rank, where the id stays out of range and predicts 0); the
         additive sums are all-reduced."""
-        import torch
         from pmf_hip import MAX_LABELS
         comm, ctx = self._comm, self._ctx
         labels = np.unique(y)
@@ -223,13 +201,10 @@ class DeviceModel:
         mine = (vu >= lo) & ((vu < hi) | last)
         lu = np.where(vu[mine] < self.n_users, vu[mine] - lo, np.iinfo(np.int32).max)
         have = ctx.eval_set(lu, vi[mine], y[mine], labels=labels) if mine.any() else False
-        dev = self._device_obj()
 
         def run():
             sums = ctx.eval_sums(self._uses_bias, offset) if have else np.zeros(2 + 2 * MAX_LABELS)
-            t = torch.from_numpy(sums).to(dev)
-            comm.all_reduce(t)
-            return ctx.metrics_from_sums(t.cpu().numpy())
+            return ctx.metrics_from_sums(comm.all_reduce_host(sums))
         return run
 
     def _record(self, rmse_v, mae_v):
@@ -244,7 +219,6 @@ class DeviceModel:
 
     def close(self):
         """Release the device context(s) (predict is unavailable afterwards)."""
-        self._exit_stream()
         for name in ("_ctx", "_shard_ctx"):
             ctx = getattr(self, name, None)
             if ctx is not None:

@@ -28,9 +28,27 @@ class GaussianHost(DeviceModel):
 
     @property
     def V_theta(self):
+        """(n_users, K, K) float64.  After a SHARDED fit this is only THIS RANK's user range
+        (rows `user_range`): an attribute read must not hide a collective (a rank-0-only read
+        would deadlock the job, and the full stack is U x K x K x 8 bytes on every rank).  All ranks
+        together call `gather_V_theta()` for the full stack."""
         if self._V_theta is None and self._ctx is not None:
-            self._V_theta = self._gather_users(self._train_ctx().get_array(USER, ARR_COV))
+            self._V_theta = self._train_ctx().get_array(USER, ARR_COV)
         return self._V_theta
+
+    @property
+    def user_range(self):
+        """[lo, hi) of the users this rank trained (all users when not sharded)."""
+        if self._comm is None or self._bounds is None:
+            return 0, self.n_users
+        return int(self._bounds[self._comm.rank]), int(self._bounds[self._comm.rank + 1])
+
+    def gather_V_theta(self):
+        """Collective after a sharded fit: every rank gets the full (n_users, K, K) covariance stack
+        (broadcast in 64 MB row blocks).  Equals `V_theta` when not sharded."""
+        if self._comm is None:
+            return self.V_theta
+        return self._user_array(ARR_COV, self._train_ctx())
 
     @V_theta.setter
     def V_theta(self, value):
@@ -58,11 +76,11 @@ class GaussianHost(DeviceModel):
         self._V_theta = self._V_beta = None
 
     def _pull_state(self):
-        ctx, g = self._ctx, self._gather_users
-        self.m_theta, self.m_beta = g(ctx.get_array(USER, ARR_FACTOR)), ctx.get_array(ITEM, ARR_FACTOR)
+        ctx, g = self._ctx, self._user_array
+        self.m_theta, self.m_beta = g(ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
         arrays = [(USER, ARR_FACTOR, self.m_theta), (ITEM, ARR_FACTOR, self.m_beta)]
         if self._uses_bias:
-            self.m_user_bias, self.m_item_bias = g(ctx.get_array(USER, ARR_BIAS)), ctx.get_array(ITEM, ARR_BIAS)
+            self.m_user_bias, self.m_item_bias = g(ARR_BIAS), ctx.get_array(ITEM, ARR_BIAS)
             arrays += [(USER, ARR_BIAS, self.m_user_bias), (ITEM, ARR_BIAS, self.m_item_bias)]
         self._V_theta = self._V_beta = None
         if self._comm is not None:
@@ -74,9 +92,6 @@ class GaussianHost(DeviceModel):
     def _prepare(self, ctx):
         ctx.set_cov_identity(USER, 1.0)
         ctx.set_cov_identity(ITEM, 1.0)
-        self._stats = (None, None)
-        if self._comm is not None:
-            self._stats = pdist.gauss_stats(ctx, self._device_obj())
 
     @staticmethod
     def _should_stop(improvement, tol):
@@ -84,7 +99,7 @@ class GaussianHost(DeviceModel):
 
     def _iterate(self, ctx):
         cfg = self.config
-        pdist.gaussian_iteration(ctx, self._comm, self._stats[0], self._stats[1], cfg.sigma2, cfg.eta_theta2,
+        pdist.gaussian_iteration(ctx, self._comm, None, None, cfg.sigma2, cfg.eta_theta2,
                                  cfg.eta_beta2, cfg.eta_bias2 if self._uses_bias else None)
 
     def fit(self, train_df, val_df=None, global_mean=0.0):

@@ -50,11 +50,9 @@ class GaussianMFSGD(GaussianHost):
         return improvement < tol
 
     def _prepare(self, ctx):
-        self._stats = None
-        if self._comm is not None:
-            self._stats = pdist.sgd_stats(ctx, self._device_obj())
+        pass
 
     def _iterate(self, ctx):
         cfg = self.config
-        pdist.gaussian_sgd_iteration(ctx, self._comm, self._stats, cfg.lr, cfg.sigma2, cfg.eta_theta2,
+        pdist.gaussian_sgd_iteration(ctx, self._comm, None, cfg.lr, cfg.sigma2, cfg.eta_theta2,
                                      cfg.eta_beta2, cfg.eta_bias2)

@@ -65,12 +65,12 @@ class HPF_CAVI(DeviceModel):
         self.E_eta = self.gamma_a_eta / self.gamma_b_eta
 
     def _pull_state(self):
-        ctx, g = self._ctx, self._gather_users
-        self.gamma_a_theta, self.gamma_b_theta = g(ctx.get_array(USER, ARR_SHAPE)), g(ctx.get_array(USER, ARR_RATE))
+        ctx, g = self._ctx, self._user_array
+        self.gamma_a_theta, self.gamma_b_theta = g(ARR_SHAPE), g(ARR_RATE)
         self.gamma_a_beta, self.gamma_b_beta = ctx.get_array(ITEM, ARR_SHAPE), ctx.get_array(ITEM, ARR_RATE)
-        self.E_theta, self.E_beta = g(ctx.get_array(USER, ARR_FACTOR)), ctx.get_array(ITEM, ARR_FACTOR)
-        self.gamma_b_xi, self.gamma_b_eta = g(ctx.get_array(USER, ARR_HYPER_RATE)), ctx.get_array(ITEM, ARR_HYPER_RATE)
-        self.E_xi, self.E_eta = g(ctx.get_array(USER, ARR_PRIOR_RATE)), ctx.get_array(ITEM, ARR_PRIOR_RATE)
+        self.E_theta, self.E_beta = g(ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
+        self.gamma_b_xi, self.gamma_b_eta = g(ARR_HYPER_RATE), ctx.get_array(ITEM, ARR_HYPER_RATE)
+        self.E_xi, self.E_eta = g(ARR_PRIOR_RATE), ctx.get_array(ITEM, ARR_PRIOR_RATE)
         if self._comm is not None:
             self._finish_sharded([(USER, ARR_FACTOR, self.E_theta), (ITEM, ARR_FACTOR, self.E_beta)])
 
@@ -84,7 +84,6 @@ class HPF_CAVI(DeviceModel):
         ctx.set_array(ITEM, ARR_FACTOR, self.E_beta)
         ctx.set_array(USER, ARR_PRIOR_RATE, self._mine(self.E_xi))
         ctx.set_array(ITEM, ARR_PRIOR_RATE, self.E_eta)
-        stats = pdist.gamma_stats(ctx, self._device_obj()) if self._comm is not None else None
         user_prior = (cfg.a, 0.0, True, self.gamma_a_xi, cfg.b_prime)
         item_prior = (cfg.c, 0.0, True, self.gamma_a_eta, cfg.d_prime)
         monitor = self._monitor_setup(val_df)
@@ -93,7 +92,7 @@ class HPF_CAVI(DeviceModel):
             if cfg.verbose:
                 print(f"\nHPF_CAVI iteration {it}/{cfg.max_iter}")
             # theta then xi (hpf_cavi.py:126-159); beta then eta (hpf_cavi.py:162-193)
-            self._run_iteration(lambda: pdist.gamma_iteration(ctx, self._comm, stats, user_prior, item_prior))
+            self._run_iteration(lambda: pdist.gamma_iteration(ctx, self._comm, None, user_prior, item_prior))
             self._tick(it)
             if monitor is None:
                 continue

@@ -9,10 +9,20 @@ evaluates each softplus table once per call instead of once per access; the
 value and gradients are unchanged (pinned by tests/golden/hpf_torch.npz)."""
 from dataclasses import dataclass
 
+import sys
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+_engine = sys.modules.get("pmf_hip")
+if _engine is not None and _engine.loaded_before_torch() and not torch.cuda.is_available():
+    # libpmf_hip.so mapped /opt/rocm's HIP runtime before torch could map its bundled one
+    warnings.warn("torch was imported after the first pmf_hip engine call and finds no GPU: import torch "
+                  "(or this module) before fitting a CAVI model, or set PMF_HIP_TORCH_PRELOAD=1; "
+                  "HPF_PyTorch will run on the CPU in this process", RuntimeWarning, stacklevel=2)
 
 
 @dataclass

@@ -46,10 +46,10 @@ class PoissonMFCAVI(DeviceModel):
         self.E_beta = self.a_beta / self.b_beta
 
     def _pull_state(self):
-        ctx, g = self._ctx, self._gather_users
-        self.a_theta, self.b_theta = g(ctx.get_array(USER, ARR_SHAPE)), g(ctx.get_array(USER, ARR_RATE))
+        ctx, g = self._ctx, self._user_array
+        self.a_theta, self.b_theta = g(ARR_SHAPE), g(ARR_RATE)
         self.a_beta, self.b_beta = ctx.get_array(ITEM, ARR_SHAPE), ctx.get_array(ITEM, ARR_RATE)
-        self.E_theta, self.E_beta = g(ctx.get_array(USER, ARR_FACTOR)), ctx.get_array(ITEM, ARR_FACTOR)
+        self.E_theta, self.E_beta = g(ARR_FACTOR), ctx.get_array(ITEM, ARR_FACTOR)
         if self._comm is not None:
             self._finish_sharded([(USER, ARR_FACTOR, self.E_theta), (ITEM, ARR_FACTOR, self.E_beta)])
 
@@ -61,16 +61,15 @@ class PoissonMFCAVI(DeviceModel):
         ctx = self._open_context(u, i, x)
         ctx.set_array(USER, ARR_FACTOR, self._mine(self.E_theta))
         ctx.set_array(ITEM, ARR_FACTOR, self.E_beta)
-        stats = pdist.gamma_stats(ctx, self._device_obj()) if self._comm is not None else None
         prior = (cfg.a0, cfg.b0, False, 0.0, 0.0)
         monitor = self._monitor_setup(val_df)
         previous = None
         for it in range(1, cfg.max_iter + 1):
             if cfg.verbose:
                 print(f"\nCAVI iteration {it}/{cfg.max_iter}")
-            # users (poisson_mf_cavi.py:135-170) then items (:173-200); with a Comm the item
-            # half-sweep is accumulate -> all-reduce -> finalize
-            self._run_iteration(lambda: pdist.gamma_iteration(ctx, self._comm, stats, prior, prior))
+            # users (poisson_mf_cavi.py:135-170) then items (:173-200); with a Comm the library runs
+            # the item half-sweep as accumulate -> all-reduce -> finalize
+            self._run_iteration(lambda: pdist.gamma_iteration(ctx, self._comm, None, prior, prior))
             self._tick(it)
             if monitor is None:
                 continue

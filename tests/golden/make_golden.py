@@ -229,6 +229,58 @@ def gen_model_case(kind, seed, K):
     return out
 
 
+# ---- headline / reference-config K ---------------------------------------------------------------
+# BASELINE.json quotes K = 64 and K = 128; the reference's own configurations are K = 30 (Gaussian),
+# 40 (Poisson) and 20 (HPF) (best_hyperparams.txt:3-5).  A smaller problem (120 users x 48 items,
+# 1600 ratings, same edge cases) keeps the reference's (n, K, K) stacks and the fixtures small:
+# state after 3 iterations (means / expectations in full, covariances as diagonals plus one full matrix
+# per side), predict, and the validation RMSE / MacroMAE after each of 5 iterations (which pins the
+# whole state at every iteration through the reference's own evaluate_* functions).
+HEADLINE = [("gauss_bias", 30), ("gauss_bias", 64), ("gauss_bias", 128), ("gauss", 64),
+            ("poisson", 40), ("poisson", 64), ("hpf", 20), ("hpf", 64)]
+HEADLINE_KEYS = {"gauss_bias": ["m_theta", "m_beta", "m_user_bias", "m_item_bias"], "gauss": ["m_theta", "m_beta"],
+                 "poisson": ["E_theta", "E_beta", "a_theta", "b_beta"],
+                 "hpf": ["E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_theta", "gamma_b_beta", "gamma_b_xi", "gamma_b_eta"]}
+HL_PRED_U = np.array([0, 1, 2, 119, 120, 5, 17, 111, 100, 1000], dtype=np.int64)
+HL_PRED_I = np.array([0, 47, 48, 3, 2, 5, 41, 7, 100, 1], dtype=np.int64)
+
+
+def gen_headline_case(kind, K, seed=11):
+    train_raw, val_raw = tiny_problem(2000 + K, n_users=120, n_items=48, nnz=1600)
+    train, val, gm = preprocess(kind, train_raw, val_raw)
+    is_gauss = kind in ("gauss_bias", "gauss")
+    out = {"train_u": train["u"].to_numpy(), "train_i": train["i"].to_numpy(),
+           "train_rating": train["rating"].to_numpy(dtype=float),
+           "val_u": val["u"].to_numpy(), "val_i": val["i"].to_numpy(), "val_rating": val["rating"].to_numpy(dtype=float),
+           "global_mean": np.float64(gm), "pred_u": HL_PRED_U, "pred_i": HL_PRED_I}
+    base = dict(BASE_CFG[kind], n_factors=K, random_state=seed, verbose=False)
+    meta = {"kind": kind, "seed": seed, "K": K, "base_cfg": BASE_CFG[kind], "iters": [3], "traj_iters": 5, "cov_rows": [7]}
+    traj_rmse, traj_mae = [], []
+    for n_it in range(1, 6):
+        m = make(kind, dict(base, max_iter=n_it, tol=(0.0 if is_gauss else None)))
+        if is_gauss:
+            m.fit(train, global_mean=gm)
+            traj_rmse.append(m.evaluate_rmse(val, gm))
+            traj_mae.append(m.evaluate_macro_mae(val, gm) if kind == "gauss_bias" else np.nan)
+        else:
+            m.fit(train)
+            traj_rmse.append(m.evaluate_rmse(val))
+            traj_mae.append(m.evaluate_macro_mae(val))
+        if n_it == 3:
+            for key in HEADLINE_KEYS[kind]:
+                out[f"it{n_it}_{key}"] = np.asarray(getattr(m, key))
+            if is_gauss:
+                for side in ("theta", "beta"):
+                    V = getattr(m, f"V_{side}")
+                    out[f"it{n_it}_V_{side}_diag"] = np.einsum("nkk->nk", V)
+                    out[f"it{n_it}_V_{side}_rows"] = V[meta["cov_rows"]]
+        if n_it == 3:
+            out["it3_predict"] = m.predict(HL_PRED_U, HL_PRED_I, gm) if is_gauss else m.predict(HL_PRED_U, HL_PRED_I)
+    out["traj_val_rmse"], out["traj_val_macro_mae"] = np.array(traj_rmse), np.array(traj_mae)
+    out["meta"] = np.array(json.dumps(meta))
+    return out
+
+
 def gen_metrics():
     rng = np.random.default_rng(5)
     y_true = rng.choice(6, size=500, p=[0.032, 0.006, 0.012, 0.036, 0.142, 0.772]).astype(float)
@@ -311,6 +363,13 @@ def gen_hpf_torch():
 
 def main():
     only = sys.argv[1:]
+    if not only or "headline" in only:
+        for kind, K in HEADLINE:
+            path = os.path.join(OUT, f"hk_{kind}_k{K}.npz")
+            np.savez_compressed(path, **gen_headline_case(kind, K))
+            print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+        if only:
+            return
     for kind in ("hpf", "poisson", "gauss_bias", "gauss", "poisson_ext"):
         if only and kind not in only:
             continue

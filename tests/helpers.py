@@ -46,3 +46,27 @@ def rel_err(a, b, floor=1e-12):
 
 def max_abs(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0
+
+
+# ---- caller-owned device statistics buffers (the bring-your-own-collective form of the C-ABI:
+# pmf_*_accumulate / pmf_*_finalize) -- torch is test infrastructure here, the product path
+# (pmf_hip.dist.Comm) keeps its buffers inside libpmf_hip.so
+class DeviceStats:
+    def __init__(self, n_elems, np_dtype, device):
+        import torch
+        tdt = torch.float64 if np_dtype == np.float64 else torch.float32
+        self.tensor = torch.zeros(int(n_elems), dtype=tdt, device=device)
+        self.ptr = self.tensor.data_ptr()
+
+
+def gamma_stats(ctx, device):
+    return DeviceStats(ctx.n_items * 2 * ctx.kpad, ctx.np_dtype, device)
+
+
+def sgd_stats(ctx, device):
+    return DeviceStats(ctx.n_items * ctx.sgd_stats_width, ctx.np_dtype, device)
+
+
+def gauss_stats(ctx, device):
+    return (DeviceStats(ctx.n_items * (ctx.cov_stride + ctx.kpad), ctx.np_dtype, device),
+            DeviceStats(ctx.n_items * 2, ctx.np_dtype, device))

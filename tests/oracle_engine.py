@@ -11,6 +11,35 @@ from oracle import cavi_oracle as orc
 USER, ITEM = 0, 1
 
 
+class GlooComm:
+    """An EXTERNAL collective for `pmf_hip.dist` (the bring-your-own-communicator form): torch.distributed
+    over gloo, CPU tensors.  `in_library = False` makes the iteration functions sequence
+    accumulate -> all_reduce -> finalize themselves."""
+
+    in_library = False
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce(self, tensor):
+        self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
+    def all_reduce_async(self, tensor):
+        return self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def all_reduce_host(self, values, op="sum"):
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64).reshape(-1))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM, group=self.group)
+        return t.numpy().reshape(np.shape(values))
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+
 class CpuStats:
     def __init__(self, n_elems):
         import torch

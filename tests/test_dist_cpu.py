@@ -1,6 +1,9 @@
-"""Multi-process (world_size 2, gloo, CPU) test of the user-sharded iteration
-orchestration in pmf_hip.dist: shard -> local half-sweeps -> all-reduce of the
-item statistics -> finalise, against the unsharded oracle."""
+"""Multi-process (world_size 2, gloo, CPU) tests of the user-sharded iteration in pmf_hip.dist:
+shard -> local half-sweeps -> all-reduce of the item statistics -> finalise, against the unsharded
+oracle.  On a GPU the collective runs inside libpmf_hip.so (pmf_comm_init); here the same iteration
+functions drive an oracle-backed engine through their external-collective form (accumulate ->
+collective -> finalize sequenced by the host), and `test_sharded_model_fit_*` runs the model
+classes' sharded `fit` host logic (sharding, monitor all-reduce, gather) the same way."""
 import os
 import socket
 import sys
@@ -27,10 +30,10 @@ def _worker(rank, world, port, kind, out_dir, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as tdist
     from oracle import cavi_oracle as orc
-    from oracle_engine import CpuStats, OracleEngine
+    from oracle_engine import CpuStats, GlooComm, OracleEngine
     from pmf_hip import dist as pdist
     tdist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = pdist.Comm()
+    comm = GlooComm()
     u, i, x = _problem()
     U, I, K = 400, 60, 6
     bounds = pdist.shard_bounds(u, U, world)

@@ -4,7 +4,7 @@ reproduce the unsharded (fused-kernel) result."""
 import numpy as np
 import pytest
 
-from helpers import max_abs, rel_err, skewed_problem
+from helpers import gamma_stats, gauss_stats, max_abs, rel_err, skewed_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def test_hpf_logical_shards_equal_single_context(K, dtype, tol):
     ref = new_ctx(U, u, i, x, 0, U)
     b, parts = _shards(u, i, x, U, W)
     ctxs = [new_ctx(int(b[g + 1] - b[g]), *parts[g], int(b[g]), int(b[g + 1])) for g in range(W)]
-    stats = [pdist.gamma_stats(c, dev) for c in ctxs]
+    stats = [gamma_stats(c, dev) for c in ctxs]
     for _ in range(3):
         pdist.gamma_iteration(ref, None, None, up, ip)
         for c in ctxs:
@@ -71,7 +71,7 @@ def test_hpf_logical_shards_equal_single_context(K, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 2e-4)])
-@pytest.mark.parametrize("K", [16, 64, 96])
+@pytest.mark.parametrize("K", [16, 64, 96, 128])
 def test_gaussian_logical_shards_equal_single_context(K, dtype, tol):
     import torch
     import pmf_hip
@@ -93,7 +93,7 @@ def test_gaussian_logical_shards_equal_single_context(K, dtype, tol):
     ref = new_ctx(U, u, i, x, 0, U)
     b, parts = _shards(u, i, x, U, W)
     ctxs = [new_ctx(int(b[g + 1] - b[g]), *parts[g], int(b[g]), int(b[g + 1])) for g in range(W)]
-    stats = [pdist.gauss_stats(c, dev) for c in ctxs]
+    stats = [gauss_stats(c, dev) for c in ctxs]
     for _ in range(2):
         pdist.gaussian_iteration(ref, None, None, None, 0.3, 0.5, 0.5, 1.0)
         for c in ctxs:
@@ -144,7 +144,7 @@ def test_hpf_item_row_chunks_do_not_change_the_result(K, dtype):
         c.set_row_chunks(ITEM, chunks)                       # after set_ratings: lists are rebuilt
         c.set_array(USER, ARR_FACTOR, st["E_theta"]); c.set_array(ITEM, ARR_FACTOR, st["E_beta"])
         c.set_array(USER, ARR_PRIOR_RATE, st["E_xi"]); c.set_array(ITEM, ARR_PRIOR_RATE, st["E_eta"])
-        s = pdist.gamma_stats(c, dev)
+        s = gamma_stats(c, dev)
         for _ in range(2):
             c.gamma_sweep(USER, *up)
             for k in range(c.n_chunks[ITEM]):
@@ -167,7 +167,7 @@ def test_hpf_item_row_chunks_do_not_change_the_result(K, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("K", [16, 64, 96])
+@pytest.mark.parametrize("K", [16, 64, 96, 128])
 def test_gaussian_item_row_chunks_do_not_change_the_result(K, dtype):
     import torch
     import pmf_hip
@@ -186,7 +186,7 @@ def test_gaussian_item_row_chunks_do_not_change_the_result(K, dtype):
         c.set_array(USER, ARR_FACTOR, st["m_theta"]); c.set_array(ITEM, ARR_FACTOR, st["m_beta"])
         c.set_cov_identity(USER); c.set_cov_identity(ITEM)
         c.set_array(USER, ARR_BIAS, np.zeros(U)); c.set_array(ITEM, ARR_BIAS, np.zeros(I))
-        s, sb = pdist.gauss_stats(c, dev)
+        s, sb = gauss_stats(c, dev)
         for _ in range(2):
             c.gauss_factor_sweep(USER, 0.3, 0.5)
             for k in range(c.n_chunks[ITEM]):

@@ -134,15 +134,27 @@ def test_tune_all_models_concurrent_trials_write_a_loadable_file(workdir, monkey
         shutil.move("best_hyperparams.keep", "best_hyperparams.txt")
 
 
-def test_engine_first_then_torch_still_sees_the_gpu():
-    """Load order regression: torch bundles its own HIP runtime; the binding must
-    not leave the process in a state where torch.cuda is unavailable."""
+def test_engine_and_torch_share_a_process_when_torch_is_imported_first():
+    """Load order contract: the CAVI engine never imports torch; torch bundles its own HIP runtime and has to
+    be mapped before libpmf_hip.so pulls in /opt/rocm's.  torch first (what the mixed drivers and
+    hpf_pytorch do at import time): both see the GPU.  Engine first: the engine keeps working, the late
+    torch import is flagged (pmf_hip.loaded_before_torch) and PMF_HIP_TORCH_PRELOAD=1 restores the old order."""
     import subprocess
     import sys
-    code = ("import sys; sys.path.insert(0, %r); import pmf_hip; c = pmf_hip.Context(4, 4, 4); c.close(); "
-            "import torch; assert torch.cuda.is_available(); print('ok')") % os.path.join(
-                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prob-matrix-factorization_amd")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prob-matrix-factorization_amd")
+    first = ("import sys; sys.path.insert(0, %r); import src.experiments.compare_models, pmf_hip; "
+             "c = pmf_hip.Context(4, 4, 4); c.close(); import torch; "
+             "assert torch.cuda.is_available() and not pmf_hip.loaded_before_torch(); print('ok')") % pkg
+    out = subprocess.run([sys.executable, "-c", first], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    late = ("import sys; sys.path.insert(0, %r); import pmf_hip; c = pmf_hip.Context(4, 4, 4); c.close(); "
+            "assert 'torch' not in sys.modules and pmf_hip.loaded_before_torch(); print('ok')") % pkg
+    out = subprocess.run([sys.executable, "-c", late], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    pre = ("import sys; sys.path.insert(0, %r); import pmf_hip; c = pmf_hip.Context(4, 4, 4); c.close(); import torch; "
+           "assert torch.cuda.is_available() and not pmf_hip.loaded_before_torch(); print('ok')") % pkg
+    out = subprocess.run([sys.executable, "-c", pre], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, PMF_HIP_TORCH_PRELOAD="1"))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 

@@ -111,7 +111,7 @@ def _oracle_vs_device(K, dtype, bias, U=1500, I=300, N=40000, iters=2, env=None)
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 2e-4)])
-@pytest.mark.parametrize("K", [1, 5, 8, 16, 30, 32, 64, 100, 128])
+@pytest.mark.parametrize("K", [1, 5, 8, 16, 30, 32, 45, 48, 50, 64, 72, 100, 128])
 def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
     """Direct C-ABI calls on a skewed problem: split rows, empty rows, every
     solver width (register kernels up to 64, LDS kernel above)."""
@@ -124,7 +124,7 @@ def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
         assert np.max(np.abs(got[key] - st[key]) / scale) <= tol, key
 
 
-@pytest.mark.parametrize("K", [5, 16, 20, 30, 32, 33, 40, 52, 64, 70, 100, 120, 128])
+@pytest.mark.parametrize("K", [5, 16, 20, 30, 32, 33, 40, 45, 48, 49, 50, 52, 64, 70, 100, 120, 128])
 def test_mfma_kernel_matches_generic_kernel(K, monkeypatch):
     """The fp32 fast paths (K <= 64: one wavefront per task; 64 < K <= 128: two) (MFMA outer products, fused solve) against the
     generic accumulate kernel + standalone solve on the same inputs."""

@@ -129,3 +129,46 @@ def test_medium_c1_shape(golden_dir):
             np.testing.assert_allclose(st["V_theta"][d["rows_u"][:16]], d[f"{kind}_Vtheta_rows"],
                                        rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(st["m_user_bias"].sum(), float(d[f"{kind}_bias_u_sum"]), rtol=1e-9)
+
+
+# ---- headline K (64, 128) and the reference's own K (30 / 40 / 20, best_hyperparams.txt:3-5) ----------------
+HEADLINE = sorted(glob.glob(os.path.join(HERE, "golden", "hk_*.npz")))
+HEADLINE_KEYS = {"gauss_bias": ["m_theta", "m_beta", "m_user_bias", "m_item_bias"], "gauss": ["m_theta", "m_beta"],
+                 "poisson": ["E_theta", "E_beta", "a_theta", "b_beta"],
+                 "hpf": ["E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_theta", "gamma_b_beta", "gamma_b_xi", "gamma_b_eta"]}
+
+
+def test_headline_fixture_set_is_complete():
+    names = {os.path.basename(p)[3:-4] for p in HEADLINE}
+    assert names == {"gauss_bias_k30", "gauss_bias_k64", "gauss_bias_k128", "gauss_k64", "poisson_k40", "poisson_k64",
+                     "hpf_k20", "hpf_k64"}
+    assert sum(os.path.getsize(p) for p in HEADLINE) < 2 << 20
+
+
+@pytest.mark.parametrize("path", HEADLINE, ids=[os.path.basename(p)[:-4] for p in HEADLINE])
+@pytest.mark.parametrize("vectorised", [False, True], ids=["rows", "segsum"])
+def test_headline_k_states_and_trajectory(path, vectorised):
+    """The oracle at the K values the benchmark and the reference's configurations use, against vectors the
+    reference itself produced at those K (no transitive step through K = 8 / 16)."""
+    d, meta = _load(path)
+    kind, gm = meta["kind"], float(d["global_mean"])
+    tr = (d["train_u"], d["train_i"], d["train_rating"])
+    gauss = kind.startswith("gauss")
+    st, _ = orc.fit(kind, *tr, _cfg(meta, 3, 0.0 if gauss else None), global_mean=gm, vectorised=vectorised)
+    for key in HEADLINE_KEYS[kind]:
+        np.testing.assert_allclose(st[key], d[f"it3_{key}"], rtol=1e-10, atol=1e-12, err_msg=key)
+    if gauss:
+        for side in ("theta", "beta"):
+            np.testing.assert_allclose(np.einsum("nkk->nk", st[f"V_{side}"]), d[f"it3_V_{side}_diag"], rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(st[f"V_{side}"][meta["cov_rows"]], d[f"it3_V_{side}_rows"], rtol=1e-9, atol=1e-12)
+        p = orc.predict_dot(st["m_theta"], st["m_beta"], d["pred_u"], d["pred_i"], st.get("m_user_bias"),
+                            st.get("m_item_bias"), gm)
+    else:
+        p = orc.predict_dot(st["E_theta"], st["E_beta"], d["pred_u"], d["pred_i"])
+    np.testing.assert_allclose(p, d["it3_predict"], rtol=1e-10, atol=1e-12)
+    # tol that never fires: 5 monitored iterations
+    _, hist = orc.fit(kind, *tr, _cfg(meta, meta["traj_iters"], -1.0 if gauss else None),
+                      val=(d["val_u"], d["val_i"], d["val_rating"]), global_mean=gm, vectorised=vectorised)
+    np.testing.assert_allclose(hist["val_rmse"], d["traj_val_rmse"], rtol=1e-10)
+    if kind != "gauss":
+        np.testing.assert_allclose(hist["val_macro_mae"], d["traj_val_macro_mae"], rtol=1e-10)

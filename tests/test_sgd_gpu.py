@@ -6,7 +6,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from helpers import max_abs, skewed_problem
+from helpers import max_abs, sgd_stats, skewed_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -72,7 +72,7 @@ def test_sgd_statistics_are_additive_over_user_shards():
         c.set_array(USER, ARR_FACTOR, st["m_theta"][lo:hi]); c.set_array(ITEM, ARR_FACTOR, st["m_beta"])
         c.set_array(USER, ARR_BIAS, st["m_user_bias"][lo:hi]); c.set_array(ITEM, ARR_BIAS, st["m_item_bias"])
         ctxs.append(c)
-        stats.append(pdist.sgd_stats(c, dev))
+        stats.append(sgd_stats(c, dev))
     for c, s in zip(ctxs, stats):
         c.gauss_sgd_accumulate(ITEM, s.ptr, lr, s2, eb, ebias)
     torch.cuda.synchronize()

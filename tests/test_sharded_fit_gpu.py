@@ -1,13 +1,21 @@
-"""User-sharded multi-process `fit` of the model classes: two ranks (gloo, both on
-the one GPU of the test box) must reproduce the single-process fit -- factors,
-validation trajectory, stop iteration -- and leave predict() working on every rank."""
+"""Multi-rank runs through the communicator INSIDE libpmf_hip.so (pmf_comm_init / pmf_hip.dist.Comm).
+
+The test box has one GPU and RCCL refuses two ranks on one device, so the multi-rank cases run
+over the library's rehearsal transport (`hostshm`: same chunk pipeline, same event ordering between
+the compute and the collective stream, the all-reduce itself done through shared memory), and the
+real RCCL call sequence runs with one rank.  The worker processes never import torch."""
+import json
+import multiprocessing as mp
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
 import pandas as pd
 import pytest
+
+from helpers import gamma_stats, gauss_stats
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -69,30 +77,54 @@ def _fit(kind, model, train, val):
 
 
 def _worker(rank, world, port, kind, out_dir):
+    """One rank of a sharded fit: a fresh interpreter (spawn) that must get by without torch."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", PMF_COMM_TRANSPORT="hostshm")
     os.environ["PMF_DIST_CHUNKS"] = "3"   # the messages here are too small for the default to pipeline
-    import torch.distributed as tdist
     from pmf_hip import dist as pdist
-    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = pdist.init_from_env(device=0)
+    assert comm.world == world and comm.rank == rank and comm.transport == "hostshm"
     train, val = _data()
-    model, keys = _build(kind, comm=pdist.Comm())
+    model, keys = _build(kind, comm=comm)
     pred = _fit(kind, model, train, val)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pred=pred, val_rmse=np.array(model.history_["val_rmse"]),
              iters=model.history_["iterations"], **{k: getattr(model, k) for k in keys})
     if kind == "gauss":
-        np.save(os.path.join(out_dir, f"V{rank}.npy"), model.V_theta[::97])
-    tdist.barrier()
-    tdist.destroy_process_group()
+        lo, hi = model.user_range
+        local = model.V_theta                       # this rank's rows only: no hidden collective
+        assert local.shape[0] == hi - lo
+        full = model.gather_V_theta()               # explicit collective, every rank calls it
+        assert np.array_equal(full[lo:hi], local)
+        np.save(os.path.join(out_dir, f"V{rank}.npy"), full[::97])
+    assert "torch" not in sys.modules, "the sharded CAVI path must not import torch"
+    comm.barrier()
+    model.close()
+    comm.close()
+
+
+def _spawn(kind, out_dir, world=2):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, out_dir)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join()
+            raise AssertionError("a rank hung")
+    assert [p.exitcode for p in procs] == [0] * world
 
 
 @pytest.mark.parametrize("kind", ["hpf", "poisson", "gauss"])
 def test_two_rank_fit_matches_single_process(kind, tmp_path):
-    import torch.multiprocessing as mp
     train, val = _data()
     model, keys = _build(kind)
     pred = _fit(kind, model, train, val)
-    mp.spawn(_worker, args=(2, _free_port(), kind, str(tmp_path)), nprocs=2, join=True)
+    _spawn(kind, str(tmp_path))
     for rank in range(2):
         d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         assert int(d["iters"]) == model.history_["iterations"]
@@ -109,11 +141,10 @@ def test_two_rank_gradient_mode_fit_is_consistent(tmp_path):
     """The gradient mode averages the displacements of an item's pieces, so a sharded fit is a
     different (equally valid) trajectory than the single-process one: the ranks must agree with
     each other exactly and follow the same validation curve within 3 %."""
-    import torch.multiprocessing as mp
     train, val = _data()
     model, keys = _build("sgd")
     _fit("sgd", model, train, val)
-    mp.spawn(_worker, args=(2, _free_port(), "sgd", str(tmp_path)), nprocs=2, join=True)
+    _spawn("sgd", str(tmp_path))
     d0, d1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
     for k in keys + ("pred", "val_rmse"):
         assert np.array_equal(d0[k], d1[k]), k
@@ -121,81 +152,142 @@ def test_two_rank_gradient_mode_fit_is_consistent(tmp_path):
     np.testing.assert_allclose(d0["val_rmse"], model.history_["val_rmse"], rtol=3e-2)
 
 
-@pytest.mark.parametrize("workload,chunks", [("gaussian_mf", 4), ("hpf_cavi", 4), ("gaussian_mf", 1), ("gaussian_mf_sgd", 4)])
-def test_bench_two_rank_rehearsal_keeps_item_replicas_identical(workload, chunks):
-    """bench.py launched as the driver launches it (torch.distributed.run, 2 ranks; gloo and one
-    shared GPU stand in for RCCL over two): the replicated item state must end bit-identical on
-    both ranks, i.e. kernels and collectives are ordered on the shared stream."""
-    import json
-    import subprocess
+def _bench(extra, world=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--small",
-           "--backend", "gloo", "--share-gpu", "--only", "--workload", workload, "--chunks", str(chunks)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1", "--small",
+           "--transport", "hostshm", "--share-gpu", "--only"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("workload,chunks", [("gaussian_mf", 4), ("hpf_cavi", 4), ("gaussian_mf", 1), ("gaussian_mf_sgd", 4)])
+def test_bench_two_rank_rehearsal_strong_scales_the_one_matrix(workload, chunks):
+    """bench.py launched as the driver launches it (torch.distributed.run, 2 ranks; the hostshm transport
+    and one shared GPU stand in for RCCL over two): the ONE matrix is sharded (strong scaling), the
+    replicated item state ends bit-identical on both ranks, and the ranks never import torch."""
+    res = _bench(["--workload", workload, "--chunks", str(chunks)])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert res["config"]["ratings_total"] == 5_000_000 and res["config"]["n_users"] == 100_000
+    assert 0 < res["config"]["ratings_on_rank0"] < 5_000_000
+    assert res["config"]["item_replicas_identical"] is True
+    assert res["config"]["torch_imported"] is False
+    assert res["comm_exposed_ms"] >= 0 and res["comm_allreduce_ms"] > 0
+
+
+def test_bench_two_rank_rehearsal_weak_scaling_flag():
+    res = _bench(["--workload", "hpf_cavi", "--scaling", "weak"])
+    assert res["scaling"] == "weak" and res["config"]["ratings_total"] == 10_000_000
     assert res["config"]["item_replicas_identical"] is True
 
 
-def test_pipelined_item_sweep_over_rccl_single_rank():
-    """The one-GPU box cannot hold two RCCL ranks, but it can run the real backend with one:
-    the pipelined item half-sweep (asynchronous all-reduce of statistic slices on RCCL's stream,
-    stream-ordered waits) must give exactly what the same path gives without a collective."""
+def test_single_gpu_bench_line_is_complete_and_torch_free():
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["config"]["torch_imported"] is False
+    # (--small: the 83 MB item covariance table sits in the Infinity Cache, so the HBM fraction is not
+    # bounded by 1 here as it is at the full size; only its presence is checked)
+    assert res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] > 0
+    hpf = res["also"]["hpf_cavi"]["roofline"]
+    assert hpf["bound"] == "cache_gather" and 0 < hpf["frac"] <= 1.0, hpf
+    assert set(res["also"]["f64"]) == {"gaussian_mf", "hpf_cavi"}
+
+
+def test_pipelined_item_sweep_over_real_rccl_single_rank():
+    """The one-GPU box cannot hold two RCCL ranks, but it can run the real thing with one: a context with
+    a one-rank RCCL communicator takes the in-library three-stage path (accumulate, ncclAllReduce of each
+    chunk's slice on the collective stream, event-ordered finalize) and must give bit for bit what the
+    explicit accumulate / finalize calls give on a caller-owned buffer without any collective."""
     import torch
-    import torch.distributed as tdist
     import pmf_hip
-    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER, dist as pdist
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER, TRANSPORT_RCCL, dist as pdist
+    from pmf_hip.engine import Context
     from pmf_hip.synth import synth_ratings
 
-    class Identity:           # same call sequence, no collective
-        world = 2
-
-        def all_reduce(self, t):
-            return t
-
-        def all_reduce_async(self, t):
-            class Done:
-                def wait(self):
-                    pass
-            return Done()
-
     dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
-                             device_id=dev)
+    comm = pdist.Comm(0, 1, 0, Context.comm_unique_id(), "rccl")
     try:
-        comm = pdist.Comm()
-        comm.world = 2        # take the multi-rank code path; the group itself has one rank
         U, I, N, K = 20000, 3000, 600000, 64
         u, i, r = synth_ratings(U, I, N, seed=4)
         rng = np.random.default_rng(0)
         m_u, m_i = 0.1 * rng.standard_normal((U, K)), 0.1 * rng.standard_normal((I, K))
         out = []
-        for c_obj in (comm, Identity()):
+        for with_comm in (True, False):
             ctx = pmf_hip.Context(U, I, K)
-            scope = pdist.StreamScope(ctx, dev).enter()
+            if with_comm:
+                comm.attach(ctx)
+                assert ctx.comm_info() == (1, 0, TRANSPORT_RCCL)
             ctx.set_row_chunks(ITEM, 4)
             ctx.set_ratings(u, i, r - r.mean())
             ctx.set_array(USER, ARR_FACTOR, m_u); ctx.set_array(ITEM, ARR_FACTOR, m_i)
             ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
             ctx.set_array(USER, ARR_BIAS, np.zeros(U)); ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
-            s_item, s_bias = pdist.gauss_stats(ctx, dev)
+            s_item, s_bias = gauss_stats(ctx, dev)
             for _ in range(3):
-                pdist.gaussian_iteration(ctx, c_obj, s_item, s_bias, 0.5, 1.0, 1.0, 1.0)
+                ctx.gauss_factor_sweep(USER, 0.5, 1.0)
+                if with_comm:
+                    ctx.gauss_factor_sweep(ITEM, 0.5, 1.0)
+                else:
+                    for c in range(4):
+                        ctx.select_chunk(ITEM, c); ctx.gauss_factor_accumulate(ITEM, s_item.ptr)
+                    for c in range(4):
+                        ctx.select_chunk(ITEM, c); ctx.gauss_factor_finalize(ITEM, s_item.ptr, 0.5, 1.0)
+                    ctx.select_chunk(ITEM, -1)
+                ctx.gauss_bias_sweep(USER, 0.5, 1.0)
+                if with_comm:
+                    ctx.gauss_bias_sweep(ITEM, 0.5, 1.0)
+                else:
+                    ctx.gauss_bias_accumulate(ITEM, s_bias.ptr); ctx.gauss_bias_finalize(ITEM, s_bias.ptr, 0.5, 1.0)
             out.append([ctx.get_array(s, a) for s in (USER, ITEM) for a in (ARR_FACTOR, ARR_COV, ARR_BIAS)])
-            g_item = pdist.gamma_stats(ctx, dev)
+            g_item = gamma_stats(ctx, dev)
             ctx.set_array(USER, ARR_FACTOR, np.abs(m_u) + 0.1); ctx.set_array(ITEM, ARR_FACTOR, np.abs(m_i) + 0.1)
             ctx.set_ratings(u, i, r + 1.0)
             for _ in range(3):
-                pdist.gamma_iteration(ctx, c_obj, g_item, (0.3, 0.3), (0.3, 0.3))
+                ctx.gamma_sweep(USER, 0.3, 0.3)
+                if with_comm:
+                    ctx.gamma_sweep(ITEM, 0.3, 0.3)
+                else:
+                    for c in range(4):
+                        ctx.select_chunk(ITEM, c); ctx.gamma_accumulate(ITEM, g_item.ptr)
+                    for c in range(4):
+                        ctx.select_chunk(ITEM, c); ctx.gamma_finalize(ITEM, g_item.ptr, 0.3, 0.3)
+                    ctx.select_chunk(ITEM, -1)
             out[-1] += [ctx.get_array(s, ARR_FACTOR) for s in (USER, ITEM)]
-            scope.exit()
+            if with_comm:
+                prof_sum = comm.all_reduce_host([1.0, 2.5])            # host-value collective over RCCL
+                assert np.array_equal(prof_sum, [1.0, 2.5])
+                assert np.array_equal(comm.all_reduce_host([3.0], op="max"), [3.0])
+                full = ctx.gather_user_rows(ARR_FACTOR, [0, U])        # ncclBroadcast path, one rank
+                assert np.array_equal(full, ctx.get_array(USER, ARR_FACTOR))
+                with pytest.raises(pmf_hip.PmfError):
+                    ctx.gamma_ext_sweep(ITEM, 0.3, 0.3)
             ctx.close()
         for a, b in zip(*out):
             assert np.array_equal(a, b)
     finally:
-        tdist.destroy_process_group()
+        comm.close()
+
+
+def test_comm_error_paths():
+    import pmf_hip
+    from pmf_hip.engine import Context
+    a, b = pmf_hip.Context(10, 10, 4), pmf_hip.Context(10, 10, 4)
+    try:
+        with pytest.raises(pmf_hip.PmfError, match="no communicator"):
+            b.comm_attach(a)
+        with pytest.raises(pmf_hip.PmfError, match="no communicator"):
+            a.comm_allreduce_host([1.0])
+        with pytest.raises(ValueError):
+            a.comm_init(1, 0, b"short")
+        with pytest.raises(pmf_hip.PmfError, match="rank"):
+            a.comm_init(2, 5, Context.comm_unique_id())
+        assert a.comm_info() == (1, 0, -1)
+        a.comm_destroy()   # nothing attached: a no-op
+        a.comm_barrier()   # without a communicator: a device sync
+    finally:
+        a.close(); b.close()

@@ -8,15 +8,17 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
 import torch  # noqa: E402
 import pmf_hip  # noqa: E402
 from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER, dist as pdist  # noqa: E402
 from pmf_hip.synth import BASE_SEED, synth_ratings  # noqa: E402
+from helpers import gamma_stats, gauss_stats  # noqa: E402  (caller-owned torch buffers)
 
 
 class NoComm:
     world = 2
+    in_library = False
 
     def all_reduce(self, t):
         return t
@@ -42,7 +44,7 @@ def main():
         ctx.set_array(ITEM, ARR_FACTOR, 0.1 * rng.standard_normal((I, K)))
         ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
         ctx.set_array(USER, ARR_BIAS, np.zeros(U)); ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
-        s_item, s_bias = pdist.gauss_stats(ctx, dev)
+        s_item, s_bias = gauss_stats(ctx, dev)
 
         def step(comm):
             pdist.gaussian_iteration(ctx, comm, s_item, s_bias, 0.5, 1.0, 1.0, 1.0)
@@ -51,7 +53,7 @@ def main():
         ctx.set_array(USER, ARR_FACTOR, rng.gamma(1.0, 0.3, (U, K)) + 0.1)
         ctx.set_array(ITEM, ARR_FACTOR, rng.gamma(1.0, 0.3, (I, K)) + 0.1)
         ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, 1.0)); ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, 1.0))
-        s_item = pdist.gamma_stats(ctx, dev)
+        s_item = gamma_stats(ctx, dev)
         up = ip = (0.3, 0.0, True, 0.3 + K * 0.3, 1.0)
 
         def step(comm):

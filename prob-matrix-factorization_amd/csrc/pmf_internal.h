@@ -134,6 +134,11 @@ struct pmf_ctx {
 
     int64_t device_bytes = 0;
 
+    // diagnostic switches, read from the environment once when the context is created
+    bool gauss_generic = false;    // PMF_GAUSS_GENERIC: the generic accumulate kernel instead of the MFMA ones
+    bool gauss_unfused = false;    // PMF_GAUSS_UNFUSED: accumulate and solve as separate launches
+    bool gauss_lds_solve = false;  // PMF_GAUSS_LDS_SOLVE: the block-per-row LDS solve for 64 < K <= 128
+
     // multi-GPU (pmf_comm.hip): the communicator (shared between contexts of one process, refcounted)
     // and the library-owned statistics buffers of the item half-sweeps
     // (0: factor / gamma / gradient statistics, 1: Gaussian bias statistics)

@@ -191,3 +191,50 @@ def test_hpf_pytorch_graph_replay_trains_like_the_eager_loop():
     print(f"eager {secs[0]:.3f} s, graph {secs[1]:.3f} s")     # informational: 0.085 s against 0.062 s measured
     # the graph path really replayed the 12 full batches of each of the 6 epochs; the eager one none
     assert info[0] == {"graph_replays": 0, "steps": 78} and info[1] == {"graph_replays": 72, "steps": 78}
+
+
+def test_hpf_pytorch_on_cuda_matches_the_reference_golden(golden_dir):
+    """`HPF_PyTorch` placed on the MI355X against the vectors the reference produced on its CPU
+    (tests/golden/hpf_torch.npz: hpf_pytorch.py:71-184): loss value, the four gradient tables and
+    `predict`, at fp32 tolerance; then ONE Adam step of the graph-captured training loop against the
+    same step of the eager loop, both starting from the golden parameters
+    (train_hpf_pytorch_full.py:98-108)."""
+    import copy
+    import json
+    import torch
+    from src.experiments.train_hpf_pytorch_full import adam_epochs
+    from src.models.hpf_pytorch import HPF_PyTorch, HPF_PyTorch_Config
+    d = np.load(os.path.join(golden_dir, "hpf_torch.npz"))
+    cfg = HPF_PyTorch_Config(verbose=False, **json.loads(str(d["cfg"])))
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = HPF_PyTorch(int(d["n_users"]), int(d["n_items"]), d["user_counts"], d["item_counts"], cfg)
+    for name in ("theta_uncons", "beta_uncons", "xi_uncons", "eta_uncons"):       # drawn on the CPU: reference order
+        assert np.array_equal(getattr(m, name).detach().numpy(), d[name]), name
+    m = m.to(dev)
+    bu, bi, br = (torch.from_numpy(d[k]).to(dev) for k in ("batch_u", "batch_i", "batch_r"))
+    loss = m.loss(bu, bi, br)
+    assert loss.device.type == "cuda"
+    assert loss.item() == pytest.approx(float(d["loss"]), rel=2e-6)
+    loss.backward()
+    for name, key in (("theta_uncons", "grad_theta"), ("beta_uncons", "grad_beta"), ("xi_uncons", "grad_xi"),
+                      ("eta_uncons", "grad_eta")):
+        np.testing.assert_allclose(getattr(m, name).grad.cpu().numpy(), d[key], rtol=5e-5, atol=2e-6, err_msg=key)
+    pu = np.array([0, 1, 2, 299]) % int(d["n_users"]); pi = np.array([0, 79, 80, 3]) % int(d["n_items"])
+    np.testing.assert_allclose(m.predict(pu, pi), d["predict"], rtol=2e-6)
+    # one Adam step over exactly one full batch: graph replay vs eager, from the golden parameters
+    m.zero_grad(set_to_none=True)
+    eager, graphed = copy.deepcopy(m), copy.deepcopy(m)
+    n = len(br)
+    for model, use_graph in ((eager, False), (graphed, True)):
+        torch.manual_seed(5)                       # same shuffle
+        adam_epochs(model, bu, bi, br, lr=1e-2, batch_size=n, epochs=1, verbose=False, graph=use_graph)
+    assert graphed.training_info_["graph_replays"] == 1 and eager.training_info_["graph_replays"] == 0
+    for name in ("theta_uncons", "beta_uncons", "xi_uncons", "eta_uncons"):
+        a, b = getattr(eager, name).detach().cpu().numpy(), getattr(graphed, name).detach().cpu().numpy()
+        assert np.abs(a - d[name]).max() > 1e-3, name                    # the step moved the parameters
+        np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-6, err_msg=name)
+        # Adam's first step moves every touched parameter by lr against the gradient's sign
+        g = d["grad_" + name.split("_")[0]]
+        moved = np.abs(g) > 1e-4
+        np.testing.assert_allclose((a - d[name])[moved], -1e-2 * np.sign(g[moved]), rtol=1e-3, atol=1e-6, err_msg=name)

@@ -59,6 +59,51 @@ WORKLOADS = {
                             label="gaussian_mf MAP by gradient steps K=64, 1Mx100k synthetic, 50M ratings"),
 }
 SMALL = dict(U=100_000, I=10_000, N=5_000_000)  # --small: quick functional run
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD (= the fp32 vector peak)
+
+
+def topk_bench(args, local_rank):
+    """`--workload topk`: top-10 items of 100k for a batch of query users at K = 64 from
+    the dense reconstruction Theta . Beta^T -- the one MFMA-bound kernel of the product.  A step = one
+    pmf_topk_items call over the batch (ids in, ranked lists out: the host legs are inside the call, the roofline
+    uses the kernel's own hipEvent time)."""
+    import pmf_hip
+    from pmf_hip import ARR_FACTOR, ITEM, USER
+    U, I, K, k = (100_000, 10_000, 64, 10) if args.small else (1_000_000, 100_000, 64, 10)
+    if args.factors:
+        K = args.factors
+    Q = 32_768 if args.small else 262_144
+    rng = np.random.default_rng(0)
+    ctx = pmf_hip.Context(U, I, K, dtype="f32", device=local_rank)
+    ctx.set_array(USER, ARR_FACTOR, rng.gamma(0.5, 1.0, (U, K)))
+    ctx.set_array(ITEM, ARR_FACTOR, rng.gamma(0.5, 1.0, (I, K)))
+    users = rng.permutation(U)[:Q].astype(np.int32)
+    for _ in range(max(args.warmup, 1)):
+        ctx.topk_items(users[:4096], k)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items, scores = ctx.topk_items(users, k)
+    elapsed = time.perf_counter() - t0
+    ms, launches = ctx.prof_get()["topk"]
+    flops = 2.0 * Q * I * K * args.steps
+    ach = flops / (ms * 1e-3) / 1e12
+    # spot check against a NumPy ranking (exact fp32 tables, fp64 products)
+    A, B = ctx.get_array(USER, ARR_FACTOR)[users[:64]], ctx.get_array(ITEM, ARR_FACTOR)
+    want = np.argsort(-(A @ B.T), axis=1, kind="stable")[:, :k]
+    agree = float(np.mean(items[:64] == want))
+    ctx.close()
+    print(json.dumps({
+        "metric": f"query users/sec, top-{k} of {I} items from Theta.Beta^T, K={K}", "value": Q * args.steps / elapsed,
+        "unit": "users/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"top-{k} items for {Q} query users, {U}x{I} factors, K={K}" + (" [--small]" if args.small else ""),
+                   "kernel_users_per_s": Q * args.steps / (ms * 1e-3), "agreement_with_numpy_ranking": agree,
+                   "torch_imported": "torch" in sys.modules},
+        "roofline": {"kernel": "topk_fused", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / max(launches, 1),
+                     "launches": launches}}), flush=True)
 
 
 def algorithmic_bytes(workload, U, I, N, K, elem=4):
@@ -187,7 +232,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="gaussian_mf")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["topk"], default="gaussian_mf")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = shard the one fixed matrix by user range (default, the north star's "
@@ -215,6 +260,10 @@ def main():
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
     if args.share_gpu:
         local_rank = 0
+    if args.workload == "topk":
+        if world != 1:
+            raise SystemExit("--workload topk is a single-GPU measurement (queries are independent: replicas only)")
+        return topk_bench(args, local_rank)
     comm = pdist.init_from_env(device=local_rank, transport=args.transport) if world > 1 else None
     strong = args.scaling == "strong"
 

@@ -311,8 +311,12 @@ int pmf_eval_run(pmf_ctx *ctx, int use_bias, double offset, double *sum_sq_err,
 
 /* Top-k items per user from the dense reconstruction FACTOR_user . FACTOR_item^T
  * (the "identical top-k item rankings" check of the north star; the reference
- * has no ranking API -- scores follow `predict`, ties broken by lower item id).
- * out_items / out_scores hold n_query x k entries. */
+ * has no ranking API -- scores follow `predict`: `use_bias` is predict's flag, 0, PMF_PREDICT_BIAS
+ * (+ BIAS_user[u] + BIAS_item[i]) or PMF_PREDICT_SCALE (x SCALE_user[u] SCALE_item[i], the extended
+ * Poisson model); ties are broken by the lower item id, NaN scores never rank).
+ * out_items / out_scores hold n_query x k entries (-1 / 0 when fewer than k items rank).
+ * fp32 contexts with Kpad <= 128 and k <= 64 run one fused kernel: score tiles on the matrix cores
+ * (v_mfma_f32_32x32x2_f32), the running k best per user in LDS, no score matrix in HBM. */
 int pmf_topk_items(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int k, int use_bias,
                    int32_t *out_items, double *out_scores);
 

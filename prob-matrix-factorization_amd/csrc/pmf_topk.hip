@@ -22,8 +22,9 @@ struct TopkParams {
 };
 
 // 32 users x 32 items per wavefront, 4 item tiles per block.
+// (bu / bi: BIAS arrays when mode == PMF_PREDICT_BIAS, SCALE arrays when mode == PMF_PREDICT_SCALE, else null)
 __global__ __launch_bounds__(256) void topk_scores_f32_kernel(TopkParams p, const float *fu, const float *fi,
-                                                              const float *bu, const float *bi, float *scores) {
+                                                              const float *bu, const float *bi, int mode, float *scores) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, c = lane & 31;
     const int q0 = blockIdx.x * 32;
@@ -53,13 +54,14 @@ __global__ __launch_bounds__(256) void topk_scores_f32_kernel(TopkParams p, cons
     }
     // C/D layout: col = lane & 31 (item), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (user)
     const float bcol = (bi && it < p.n_items) ? bi[it] : 0.f;
+    const bool scale = mode == PMF_PREDICT_SCALE;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int qq = q0 + row;
         if (qq < p.nq && it < p.n_items) {
             float s = acc[r];
-            if (bu) s = bu[p.users[qq]] + bcol + s;
+            if (bu) s = scale ? s * (bu[p.users[qq]] * bcol) : bu[p.users[qq]] + bcol + s;
             scores[(int64_t)qq * p.n_items + it] = s;
         }
     }
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void topk_scores_f32_kernel(TopkParams p, cons
 
 // fp64 contexts: plain dot products (parity mode, not a throughput path)
 __global__ void topk_scores_f64_kernel(TopkParams p, const double *fu, const double *fi, const double *bu,
-                                       const double *bi, double *scores) {
+                                       const double *bi, int mode, double *scores) {
     const int64_t total = (int64_t)p.nq * p.n_items;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int q = (int)(e / p.n_items);
@@ -76,7 +78,7 @@ __global__ void topk_scores_f64_kernel(TopkParams p, const double *fu, const dou
         const double *a = fu + (int64_t)user * p.kpad, *b = fi + it * p.kpad;
         double s = 0.0;
         for (int k = 0; k < p.K; ++k) s = fma(a[k], b[k], s);
-        if (bu) s = bu[user] + bi[it] + s;
+        if (bu) s = mode == PMF_PREDICT_SCALE ? s * (bu[user] * bi[it]) : bu[user] + bi[it] + s;
         scores[e] = s;
     }
 }
@@ -228,6 +230,279 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int n
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// fused score + select, fp32, Kpad <= 128, k <= 64: scores never touch HBM
+// ---------------------------------------------------------------------------
+// One wavefront owns 32 query users for a whole segment of the item range.  Its A operand -- the 32
+// users' factor rows -- is loaded ONCE into KH registers per lane (lane (i = l & 31, h = l >> 5) holds
+// elements [h KH, (h + 1) KH) of user i: the k order of the MFMA steps is a permutation, the same one for
+// both operands) and stays there; per 32-item tile the lane loads the matching half of item (l & 31)'s row
+// (KH / 4 16-byte loads, double-buffered; the 25.6 MB item table is L2 / Infinity-Cache resident and the
+// four waves of a block walk it together), runs KH v_mfma_f32_32x32x2_f32 and compares its 16 scores with
+// the users' current k-th best.  Almost every tile ends there (a user's list changes about k ln(N / k)
+// times over N items); a score that does qualify is inserted into that user's sorted list in LDS by the
+// lanes of the wave in parallel (lane e holds entry e: one compare, one ballot, one shift), in ascending
+// item order, so ties keep the lower item id.  With few query users the item range is cut into segments
+// (gridDim.y) so that the chip is filled; a merge kernel then picks the k best of the segments' lists.
+#define TOPK_NEG_INF (-__builtin_inff())
+
+template <int KH, int MODE>
+__global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const float *fu, const float *fi, const float *cu,
+                                                         const float *ci, int k, int64_t seg_items, int nseg,
+                                                         float *cand_val, int32_t *cand_idx, int32_t *out_items,
+                                                         double *out_scores) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = lane >> 5, c = lane & 31;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= p.nq) return;
+    float *lv = reinterpret_cast<float *>(smem_raw) + (size_t)wave * 32 * k;           // [32][k] values, best first
+    int32_t *li = reinterpret_cast<int32_t *>(smem_raw) + (size_t)(4 + wave) * 32 * k;  // [32][k] item ids
+    const int seg = blockIdx.y;
+    const int64_t i_begin = (int64_t)seg * seg_items;
+    const int64_t i_end = i_begin + seg_items < p.n_items ? i_begin + seg_items : p.n_items;
+    const int kpad = p.kpad;
+
+    // A operand: this lane's half of user (q0 + c)'s row, resident for the whole scan
+    const int user = (q0 + c < p.nq) ? p.users[q0 + c] : -1;
+    float a[KH];
+#pragma unroll
+    for (int t = 0; t < KH; t += 4) {
+        const int kk = h * KH + t;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (user >= 0 && kk < kpad) v = *reinterpret_cast<const float4 *>(fu + (int64_t)user * kpad + kk);
+        a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
+    }
+    // per accumulator register r: the user of row (r & 3) + 8 (r >> 2) + 4 h, its bias / scale, its k-th best
+    float tau[16], ucst[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        tau[r] = qq < p.nq ? TOPK_NEG_INF : __builtin_inff();   // rows past the last query never qualify
+        ucst[r] = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
+        if (MODE != 0 && qq < p.nq) ucst[r] = cu[p.users[qq]];
+    }
+    for (int e = lane; e < 32 * k; e += 64) {
+        lv[e] = TOPK_NEG_INF;
+        li[e] = 0x7fffffff;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    auto load_tile = [&](int64_t i0, float (&b)[KH]) {
+        const int64_t it = i0 + c;
+        const bool ok = it < i_end;
+        const float *row = fi + (ok ? it : i_begin) * kpad;
+#pragma unroll
+        for (int t = 0; t < KH; t += 4) {
+            const int kk = h * KH + t;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < kpad) v = *reinterpret_cast<const float4 *>(row + kk);   // (rows of invalid items are never ranked)
+            b[t] = v.x; b[t + 1] = v.y; b[t + 2] = v.z; b[t + 3] = v.w;
+        }
+    };
+    // insert (v, item) into the list of local user `ul`; returns that list's new k-th best value
+    auto insert = [&](int ul, float v, int item) -> float {
+        float *uv = lv + ul * k;
+        int32_t *ui = li + ul * k;
+        const bool mine = lane < k;
+        const float ev = mine ? uv[lane] : 0.f;
+        const int ei = mine ? ui[lane] : 0;
+        const bool before = mine && (ev > v || (ev == v && ei < item));
+        const int pos = __popcll(__ballot(before));          // entries that rank before the candidate
+        const float pv = __shfl_up(ev, 1, 64);
+        const int pi = __shfl_up(ei, 1, 64);
+        float nv = ev;
+        int ni = ei;
+        if (lane == pos) { nv = v; ni = item; }
+        else if (lane > pos) { nv = pv; ni = pi; }
+        if (mine && pos < k) { uv[lane] = nv; ui[lane] = ni; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return __shfl(pos < k ? nv : ev, k - 1, 64);
+    };
+
+    float b0[KH], b1[KH];
+    auto tile = [&](int64_t i0, const float (&b)[KH]) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KH; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+        const int64_t it = i0 + c;
+        const bool ok = it < i_end;
+        float ccst = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
+        if (MODE != 0 && ok) ccst = ci[it];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sc = acc[r];
+            if (MODE == PMF_PREDICT_BIAS) sc = ucst[r] + ccst + sc;          // predict's order: b_u + b_i + dot
+            if (MODE == PMF_PREDICT_SCALE) sc = sc * (ucst[r] * ccst);
+            acc[r] = sc;
+            any |= ok && sc >= tau[r];
+        }
+        if (__ballot(any) == 0ull) return;
+        // rare: some score reaches its user's list.  Candidates go in ascending item order (lane order within
+        // the tile), so equal scores keep the lower item id in front.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned long long m = __ballot(ok && acc[r] >= tau[r]);
+            while (m) {
+                const int L = __builtin_ctzll(m);
+                m &= m - 1;
+                const int hh = L >> 5;
+                const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (q0 + ul >= p.nq) continue;
+                const float v = __shfl(acc[r], L, 64);
+                const float nt = insert(ul, v, (int)(i0 + (L & 31)));
+                if (h == hh) tau[r] = nt;
+            }
+        }
+    };
+    int64_t i0 = i_begin;
+    if (i0 < i_end) load_tile(i0, b0);
+    for (; i0 < i_end; i0 += 64) {
+        if (i0 + 32 < i_end) load_tile(i0 + 32, b1);
+        tile(i0, b0);
+        if (i0 + 32 >= i_end) break;
+        if (i0 + 64 < i_end) load_tile(i0 + 64, b0);
+        tile(i0 + 32, b1);
+    }
+    // hand the lists over: final result when the item range was not segmented, else this segment's candidates
+    for (int e = lane; e < 32 * k; e += 64) {
+        const int ul = e / k, t = e % k;
+        const int qq = q0 + ul;
+        if (qq >= p.nq) continue;
+        const float v = lv[e];
+        const int idx = li[e];
+        if (nseg == 1) {
+            out_items[(int64_t)qq * k + t] = idx == 0x7fffffff ? -1 : idx;
+            out_scores[(int64_t)qq * k + t] = idx == 0x7fffffff ? 0.0 : (double)v;
+        } else {
+            cand_val[((int64_t)qq * nseg + seg) * k + t] = v;
+            cand_idx[((int64_t)qq * nseg + seg) * k + t] = idx;
+        }
+    }
+}
+
+// k best of a user's nseg * k segment candidates, (value desc, item id asc); one wavefront per user
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *cand_val, const int32_t *cand_idx, int nq, int n_cand,
+                                                         int k, int32_t *out_items, double *out_scores) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const float *cv = cand_val + (int64_t)q * n_cand;
+    const int32_t *ci = cand_idx + (int64_t)q * n_cand;
+    bool have_prev = false;
+    float pv = 0.f;
+    int pi = -1;
+    for (int t = 0; t < k; ++t) {
+        bool found = false;
+        float bv = 0.f;
+        int bidx = 0x7fffffff;
+        for (int e = lane; e < n_cand; e += 64) {
+            const float v = cv[e];
+            const int i = ci[e];
+            if (i == 0x7fffffff) continue;   // an unused list slot
+            if (have_prev && !ranks_before(pv, pi, v, i)) continue;
+            if (!found || ranks_before(v, i, bv, bidx)) {
+                bv = v;
+                bidx = i;
+                found = true;
+            }
+        }
+        wave_best(bv, bidx, found);
+        if (lane == 0) {
+            out_items[(int64_t)q * k + t] = found ? bidx : -1;
+            out_scores[(int64_t)q * k + t] = found ? (double)bv : 0.0;
+        }
+        if (!found) {
+            for (int r = t + 1; r < k && lane == 0; ++r) {
+                out_items[(int64_t)q * k + r] = -1;
+                out_scores[(int64_t)q * k + r] = 0.0;
+            }
+            break;
+        }
+        have_prev = true;
+        pv = bv;
+        pi = bidx;
+    }
+}
+
+template <int KH>
+static void launch_topk_fused(pmf_ctx *ctx, const TopkParams &p, dim3 grid, size_t smem, int mode, const float *fu,
+                              const float *fi, const float *cu, const float *ci, int k, int64_t seg_items, int nseg,
+                              float *cand_val, int32_t *cand_idx, int32_t *out_items, double *out_scores) {
+    if (mode == PMF_PREDICT_BIAS)
+        hipLaunchKernelGGL((topk_fused_kernel<KH, PMF_PREDICT_BIAS>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k,
+                           seg_items, nseg, cand_val, cand_idx, out_items, out_scores);
+    else if (mode == PMF_PREDICT_SCALE)
+        hipLaunchKernelGGL((topk_fused_kernel<KH, PMF_PREDICT_SCALE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k,
+                           seg_items, nseg, cand_val, cand_idx, out_items, out_scores);
+    else
+        hipLaunchKernelGGL((topk_fused_kernel<KH, 0>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
+                           nseg, cand_val, cand_idx, out_items, out_scores);
+}
+
+// fp32, Kpad <= 128, k <= 64
+static int run_topk_fused(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int k, int mode, const float *cu,
+                          const float *ci, int32_t *out_items, double *out_scores) {
+    const int64_t I = ctx->rows[PMF_SIDE_ITEM];
+    const float *fu = (const float *)ctx->arr[PMF_SIDE_USER][PMF_ARR_FACTOR];
+    const float *fi = (const float *)ctx->arr[PMF_SIDE_ITEM][PMF_ARR_FACTOR];
+    const int64_t Q = std::min<int64_t>(n_query, 1 << 20);   // query users per launch
+    // few users: cut the item range so that the grid still has a few thousand wavefronts
+    const int64_t waves = (Q + 31) / 32;
+    int nseg = (int)std::min<int64_t>(64, std::max<int64_t>(1, 4096 / waves));
+    nseg = (int)std::min<int64_t>(nseg, std::max<int64_t>(1, I / 2048));
+    int64_t seg_items = ((I + nseg - 1) / nseg + 31) / 32 * 32;
+    nseg = (int)((I + seg_items - 1) / seg_items);
+    const size_t n_cand = nseg > 1 ? (size_t)nseg * k : 0;
+    const size_t id_bytes = ((size_t)Q * sizeof(int32_t) + 15) / 16 * 16;
+    const size_t out_i = ((size_t)Q * k * sizeof(int32_t) + 15) / 16 * 16, out_s = (size_t)Q * k * sizeof(double);
+    const size_t cv_bytes = ((size_t)Q * n_cand * sizeof(float) + 15) / 16 * 16;
+    int rc;
+    if ((rc = pmf_ensure_scratch(ctx, id_bytes + out_s + out_i + 2 * cv_bytes + 64))) return rc;
+    char *base = (char *)ctx->d_scratch;
+    double *d_out_scores = (double *)base;
+    int32_t *d_out_items = (int32_t *)(base + out_s);
+    int32_t *d_users = (int32_t *)(base + out_s + out_i);
+    float *d_cv = (float *)(base + out_s + out_i + id_bytes);
+    int32_t *d_ci = (int32_t *)(base + out_s + out_i + id_bytes + cv_bytes);
+    const size_t smem = (size_t)8 * 32 * k * sizeof(float);
+    for (int64_t at = 0; at < n_query; at += Q) {
+        const int nq = (int)std::min<int64_t>(Q, n_query - at);
+        PMF_HIP_CHECK(hipMemcpyAsync(d_users, user_ids + at, (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        TopkParams p;
+        p.users = d_users;
+        p.nq = nq;
+        p.n_items = I;
+        p.K = ctx->K;
+        p.kpad = ctx->kpad;
+        {
+            PmfProfScope prof(ctx, PMF_KERNEL_TOPK);
+            dim3 grid((unsigned)((nq + 127) / 128), (unsigned)nseg);
+            const int kh = ctx->kpad <= 16 ? 8 : ctx->kpad <= 32 ? 16 : ctx->kpad <= 64 ? 32 : 64;
+            switch (kh) {
+                case 8: launch_topk_fused<8>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                case 16: launch_topk_fused<16>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                case 32: launch_topk_fused<32>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                default: launch_topk_fused<64>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+            }
+            if (nseg > 1)
+                hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, d_cv, d_ci, nq,
+                                   (int)n_cand, k, d_out_items, d_out_scores);
+        }
+        PMF_HIP_CHECK(hipGetLastError());
+        PMF_HIP_CHECK(hipMemcpyAsync(out_items + at * k, d_out_items, (size_t)nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PMF_HIP_CHECK(hipMemcpyAsync(out_scores + at * k, d_out_scores, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return PMF_OK;
+}
+
 template <typename T>
 static int run_topk(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int k, int use_bias,
                     int32_t *out_items, double *out_scores) {
@@ -235,14 +510,21 @@ static int run_topk(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int 
     int rc;
     if ((rc = pmf_require_array(ctx, PMF_SIDE_USER, PMF_ARR_FACTOR, "pmf_topk_items"))) return rc;
     if ((rc = pmf_require_array(ctx, PMF_SIDE_ITEM, PMF_ARR_FACTOR, "pmf_topk_items"))) return rc;
+    PMF_REQUIRE(use_bias == 0 || use_bias == PMF_PREDICT_BIAS || use_bias == PMF_PREDICT_SCALE, PMF_EINVAL,
+                "pmf_topk_items: use_bias must be 0, PMF_PREDICT_BIAS or PMF_PREDICT_SCALE (got %d)", use_bias);
+    const int carr = use_bias == PMF_PREDICT_SCALE ? PMF_ARR_SCALE : PMF_ARR_BIAS;
     if (use_bias) {
-        if ((rc = pmf_require_array(ctx, PMF_SIDE_USER, PMF_ARR_BIAS, "pmf_topk_items"))) return rc;
-        if ((rc = pmf_require_array(ctx, PMF_SIDE_ITEM, PMF_ARR_BIAS, "pmf_topk_items"))) return rc;
+        if ((rc = pmf_require_array(ctx, PMF_SIDE_USER, carr, "pmf_topk_items"))) return rc;
+        if ((rc = pmf_require_array(ctx, PMF_SIDE_ITEM, carr, "pmf_topk_items"))) return rc;
     }
     const T *fu = (const T *)ctx->arr[PMF_SIDE_USER][PMF_ARR_FACTOR];
     const T *fi = (const T *)ctx->arr[PMF_SIDE_ITEM][PMF_ARR_FACTOR];
-    const T *bu = use_bias ? (const T *)ctx->arr[PMF_SIDE_USER][PMF_ARR_BIAS] : nullptr;
-    const T *bi = use_bias ? (const T *)ctx->arr[PMF_SIDE_ITEM][PMF_ARR_BIAS] : nullptr;
+    const T *bu = use_bias ? (const T *)ctx->arr[PMF_SIDE_USER][carr] : nullptr;
+    const T *bi = use_bias ? (const T *)ctx->arr[PMF_SIDE_ITEM][carr] : nullptr;
+    if constexpr (std::is_same<T, float>::value) {
+        if (ctx->kpad <= 128 && k <= 64 && !ctx->topk_two_phase)
+            return run_topk_fused(ctx, n_query, user_ids, k, use_bias, bu, bi, out_items, out_scores);
+    }
     // batch size: scores buffer of at most ~512 MB
     int64_t Q = std::max<int64_t>(32, (512ll << 20) / (I * (int64_t)sizeof(T)));
     Q = std::min<int64_t>(Q / 32 * 32, (n_query + 31) / 32 * 32);
@@ -268,11 +550,11 @@ static int run_topk(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int 
             PmfProfScope prof(ctx, PMF_KERNEL_TOPK);
             if constexpr (std::is_same<T, float>::value) {
                 dim3 grid((unsigned)((nq + 31) / 32), (unsigned)((I + 127) / 128));
-                hipLaunchKernelGGL(topk_scores_f32_kernel, grid, dim3(256), 0, ctx->stream, p, fu, fi, bu, bi, d_scores);
+                hipLaunchKernelGGL(topk_scores_f32_kernel, grid, dim3(256), 0, ctx->stream, p, fu, fi, bu, bi, use_bias, d_scores);
             } else {
                 const int64_t total = (int64_t)nq * I;
                 hipLaunchKernelGGL(topk_scores_f64_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)),
-                                   dim3(256), 0, ctx->stream, p, fu, fi, bu, bi, d_scores);
+                                   dim3(256), 0, ctx->stream, p, fu, fi, bu, bi, use_bias, d_scores);
             }
             hipLaunchKernelGGL((topk_select_kernel<T>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream,
                                d_scores, nq, I, k, d_out_items, d_out_scores);

@@ -293,10 +293,12 @@ class Context:
         return self.metrics_from_sums(self.eval_sums(use_bias, offset))
 
     def topk_items(self, user_ids, k, use_bias=False):
+        """`use_bias`: False / 0, PREDICT_BIAS (scores + b_u + b_i) or PREDICT_SCALE (scores * s_u * s_i):
+        the same flag `predict` takes, so the ranking follows the model's own score."""
         u = as_i32(user_ids, "user_ids")
         items = np.empty((len(u), k), dtype=np.int32)
         scores = np.empty((len(u), k), dtype=np.float64)
-        check(self._lib.pmf_topk_items(self._h, len(u), ptr(u, C.c_int32), int(k), int(bool(use_bias)),
+        check(self._lib.pmf_topk_items(self._h, len(u), ptr(u, C.c_int32), int(k), int(use_bias),
                                        ptr(items, C.c_int32), ptr(scores, C.c_double)), "pmf_topk_items")
         return items, scores
 

@@ -104,3 +104,65 @@ def test_fp32_engine_gives_the_reference_top10(case):
         a, b = ref[uu, items[uu]], ref[uu, want[uu]]
         assert np.allclose(a, b, rtol=1e-4, atol=1e-6), (uu, items[uu], want[uu])
     assert exact.mean() > 0.97
+
+
+@pytest.mark.parametrize("K,k,mode", [(64, 10, 0), (64, 64, 1), (128, 10, 2), (20, 7, 1), (12, 33, 0)])
+def test_fused_topk_equals_the_two_phase_path(K, k, mode, monkeypatch):
+    """The fused kernel (MFMA score tiles + running k best in LDS, item range cut into segments and merged) against
+    the two-phase path (score matrix in HBM, then select): same items, scores equal up to the summation order
+    of the two kernels; exact ties and a NaN row included."""
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_SCALE, ITEM, USER
+    rng = np.random.default_rng(K + k)
+    U, I = 700, 20011                       # not multiples of 32; 20011 items -> several segments
+    A, B = rng.gamma(0.5, 1.0, (U, K)), rng.gamma(0.5, 1.0, (I, K))
+    B[I - 1] = B[11]; B[4000] = B[11]       # exact ties across segments
+    B[77] = np.nan                          # an item whose scores are NaN never ranks
+    A[5] = 0.0                              # a user whose scores are all equal (0): k lowest item ids win
+    cu, ci = rng.gamma(1.0, 1.0, U) + 0.1, rng.gamma(1.0, 1.0, I) + 0.1
+    ci[I - 1] = ci[4000] = ci[11]
+    users = rng.permutation(U)[:333]
+    users[0] = 5
+    out = {}
+    for two_phase in (False, True):
+        if two_phase:
+            monkeypatch.setenv("PMF_TOPK_TWO_PHASE", "1")
+        with pmf_hip.Context(U, I, K, dtype="f32") as ctx:
+            ctx.set_array(USER, ARR_FACTOR, A); ctx.set_array(ITEM, ARR_FACTOR, B)
+            if mode:
+                arr = ARR_BIAS if mode == 1 else ARR_SCALE
+                ctx.set_array(USER, arr, cu); ctx.set_array(ITEM, arr, ci)
+            out[two_phase] = ctx.topk_items(users, k, use_bias=mode)
+    (fi_, fs), (ti_, ts) = out[False], out[True]
+    assert fi_.shape == (333, k) and (fi_ >= 0).all() and not (fi_ == 77).any()
+    np.testing.assert_allclose(fs, ts, rtol=3e-6, atol=1e-6)
+    assert (np.diff(fs, axis=1) <= 0).all()
+    tie = np.diff(fs, axis=1) == 0
+    assert (np.diff(fi_, axis=1)[tie] > 0).all()
+    # user 5: all scores equal (0, or the item bias order for mode 1) -> deterministic ids
+    if mode != 1:
+        want = [i for i in range(k + 1) if i != 77][:k]
+        assert list(fi_[0]) == want and list(ti_[0]) == want
+    same = fi_ == ti_
+    assert same.mean() > 0.995
+    for r, c in zip(*np.nonzero(~same)):    # only near-equal scores may swap
+        assert abs(fs[r, c] - ts[r, c]) <= 3e-6 * max(1.0, abs(ts[r, c]))
+
+
+def test_extended_poisson_top_k_follows_its_own_predict():
+    """PoissonMFExtendedCAVI ranks under its scaled score E_phi[u] E_psi[i] theta_u . beta_i."""
+    from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVI, PoissonMFExtendedCAVIConfig
+    d, meta = load_case("poisson_ext_s7_k16")
+    train, _ = frames(d)
+    m = PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(n_factors=meta["K"], random_state=meta["seed"], max_iter=5,
+                                                          tol=None, verbose=False, **meta["base_cfg"]), dtype="f64").fit(train)
+    users = np.arange(m.n_users)
+    items, scores = m.top_k_items(users, 10)
+    full = (m.E_phi[:, None] * m.E_psi[None, :]) * (m.E_theta @ m.E_beta.T)
+    assert np.array_equal(items, _rank(full, 10))
+    pred = m.predict(np.repeat(users, 10), items.reshape(-1)).reshape(-1, 10)
+    np.testing.assert_allclose(scores, pred, rtol=1e-12)
+    m32 = PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(n_factors=meta["K"], random_state=meta["seed"], max_iter=5,
+                                                            tol=None, verbose=False, **meta["base_cfg"]), dtype="f32").fit(train)
+    it32, _ = m32.top_k_items(users, 10)      # the fused fp32 kernel, scale mode
+    assert np.mean(it32 == items) > 0.97

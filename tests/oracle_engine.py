@@ -39,6 +39,18 @@ class GlooComm:
     def barrier(self):
         self._dist.barrier(group=self.group)
 
+    def attach(self, ctx):
+        """What pmf_hip.dist.Comm.attach does for a real context: from now on the context's ITEM sweeps
+        are distributed (here: by the OracleContext itself, over this communicator)."""
+        ctx.comm_attach(self)
+        return ctx
+
+
+class AttachingGlooComm(GlooComm):
+    """Looks to the model classes like pmf_hip.dist.Comm: contexts `attach` and then distribute their own ITEM
+    sweeps (`in_library = True`), so the iteration functions issue the plain fused calls."""
+    in_library = True
+
 
 class CpuStats:
     def __init__(self, n_elems):
@@ -238,3 +250,143 @@ class OracleEngine:
         f[live] += s[live, :self.K] / s[live, self.K + 1][:, None]
         b[live] += s[live, self.K] / s[live, self.K + 1]
         self.st[kf], self.st[kb] = f, b
+
+
+class OracleContext(OracleEngine):
+    """A CPU stand-in for `pmf_hip.Context` itself -- TEST ONLY -- so that the model classes' sharded
+    `fit` (sharding, attach, monitor all-reduce, gather, the full-size context at the end) can run over
+    gloo without a GPU.  With a communicator attached (`GlooComm.attach`) its ITEM sweeps run the product's
+    host-sequenced accumulate -> all-reduce -> finalize (`pmf_hip.dist._item_half_sweep`), which is what
+    libpmf_hip.so does internally on a GPU."""
+
+    NAMES = {"gamma": {(USER, 0): "E_theta", (ITEM, 0): "E_beta", (USER, 1): "a_theta", (ITEM, 1): "a_beta",
+                       (USER, 2): "b_theta", (ITEM, 2): "b_beta", (USER, 3): "E_xi", (ITEM, 3): "E_eta",
+                       (USER, 4): "gamma_b_xi", (ITEM, 4): "gamma_b_eta"},
+             "gauss": {(USER, 0): "m_theta", (ITEM, 0): "m_beta", (USER, 5): "V_theta", (ITEM, 5): "V_beta",
+                       (USER, 6): "m_user_bias", (ITEM, 6): "m_item_bias"}}
+
+    def __init__(self, n_users, n_items, n_factors, dtype="f64", device=0):
+        self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(n_factors)
+        self.kpad, self.cov_stride, self.np_dtype = self.K, self.K * self.K, np.float64
+        self.raw, self.st = {}, {}
+        self.n_chunks = {USER: 1, ITEM: 1}
+        self._cur = {USER: -1, ITEM: -1}
+        self._comm = None
+        self._eval = None
+        self.nnz = 0
+
+    # ---- data ------------------------------------------------------------
+    def set_ratings(self, u, i, x):
+        self.u, self.i, self.x = np.asarray(u, np.int64), np.asarray(i, np.int64), np.asarray(x, np.float64)
+        assert self.u.min(initial=0) >= 0 and self.u.max(initial=0) < self.n_users
+        self.idx = (orc.group_positions(self.u, self.n_users), orc.group_positions(self.i, self.n_items))
+        self.nnz = len(self.u)
+
+    def set_array(self, side, array, host):
+        self.raw[(side, array)] = np.array(host, dtype=np.float64)
+
+    def get_array(self, side, array):
+        return self.raw[(side, array)].copy()
+
+    def set_cov_identity(self, side, scale=1.0):
+        rows = self.n_users if side == USER else self.n_items
+        self.raw[(side, 5)] = np.tile(scale * np.eye(self.K), (rows, 1, 1))
+
+    def close(self):
+        pass
+
+    def comm_attach(self, comm):
+        self._comm = comm
+
+    def gather_user_rows(self, array, bounds):
+        import torch.distributed as dist
+        parts = [None] * self._comm.world
+        dist.all_gather_object(parts, self.raw[(USER, array)], group=self._comm.group)
+        assert [len(p) for p in parts] == list(np.diff(bounds))
+        return np.concatenate(parts, axis=0)
+
+    # ---- sweeps ------------------------------------------------------------
+    def _with(self, kind, fn):
+        names = self.NAMES[kind]
+        self.st = {name: self.raw[key] for key, name in names.items() if key in self.raw}
+        if kind == "gauss":
+            for key, rows in (("m_user_bias", self.n_users), ("m_item_bias", self.n_items)):
+                self.st.setdefault(key, np.zeros(rows))
+        fn()
+        for key, name in names.items():
+            if name in self.st and (key in self.raw or name not in ("m_user_bias", "m_item_bias")):
+                self.raw[key] = self.st[name]
+
+    def _item_dist(self, side, width, accumulate, finalize):
+        from pmf_hip import dist as pdist
+        rows = self.n_items
+        stats = CpuStats(rows * width)
+        pdist._item_half_sweep(self, self._comm, stats, width, lambda: accumulate(stats.ptr), lambda: finalize(stats.ptr))
+
+    def gamma_sweep(self, side, *prior):
+        def run():
+            if side == ITEM and self._comm is not None:
+                self._item_dist(side, 2 * self.K, lambda s: OracleEngine.gamma_accumulate(self, side, s),
+                                lambda s: OracleEngine.gamma_finalize(self, side, s, *prior))
+            else:
+                OracleEngine.gamma_sweep(self, side, *prior)
+        self._with("gamma", run)
+
+    def gauss_factor_sweep(self, side, sigma2, eta2):
+        def run():
+            if side == ITEM and self._comm is not None:
+                self._item_dist(side, self.K * self.K + self.K, lambda s: OracleEngine.gauss_factor_accumulate(self, side, s),
+                                lambda s: OracleEngine.gauss_factor_finalize(self, side, s, sigma2, eta2))
+            else:
+                OracleEngine.gauss_factor_sweep(self, side, sigma2, eta2)
+        self._with("gauss", run)
+
+    def gauss_bias_sweep(self, side, sigma2, eta_bias2):
+        def run():
+            if side == ITEM and self._comm is not None:
+                saved, self.n_chunks[ITEM] = self.n_chunks[ITEM], 1      # [I x 2]: one message
+                try:
+                    self._item_dist(side, 2, lambda s: OracleEngine.gauss_bias_accumulate(self, side, s),
+                                    lambda s: OracleEngine.gauss_bias_finalize(self, side, s, sigma2, eta_bias2))
+                finally:
+                    self.n_chunks[ITEM] = saved
+            else:
+                OracleEngine.gauss_bias_sweep(self, side, sigma2, eta_bias2)
+        self._with("gauss", run)
+
+    # ---- predict / monitor (engine.Context semantics) -------------------------
+    def predict(self, user_ids, item_ids, use_bias=False, offset=0.0):
+        u, i = np.asarray(user_ids, np.int64), np.asarray(item_ids, np.int64)
+        ok = (u >= 0) & (u < self.n_users) & (i >= 0) & (i < self.n_items)
+        out = np.zeros(len(u))
+        A, B = self.raw[(USER, 0)], self.raw[(ITEM, 0)]
+        out[ok] = np.einsum("nk,nk->n", A[u[ok]], B[i[ok]])
+        if use_bias:
+            out[ok] += self.raw[(USER, 6)][u[ok]] + self.raw[(ITEM, 6)][i[ok]]
+        return out + offset
+
+    def eval_set(self, user_ids, item_ids, y_true, labels=None):
+        y = np.asarray(y_true, np.float64)
+        labels = np.unique(y) if labels is None else np.asarray(labels, np.float64)
+        if len(labels) > 32 or len(y) == 0:
+            return False
+        self._eval = (np.asarray(user_ids, np.int64), np.asarray(item_ids, np.int64), y, np.searchsorted(labels, y))
+        return True
+
+    def eval_sums(self, use_bias=False, offset=0.0):
+        u, i, y, lab = self._eval
+        err = y - self.predict(u, i, use_bias, offset)
+        abs_l, cnt_l = np.zeros(32), np.zeros(32)
+        np.add.at(abs_l, lab, np.abs(err))
+        np.add.at(cnt_l, lab, 1.0)
+        return np.concatenate([[float(len(y)), float(np.sum(err * err))], abs_l, cnt_l])
+
+    @staticmethod
+    def metrics_from_sums(sums):
+        n, sse = sums[0], sums[1]
+        abs_l, cnt_l = sums[2:34], sums[34:66]
+        seen = cnt_l > 0
+        return float(np.sqrt(sse / n)), float(np.mean(abs_l[seen] / cnt_l[seen]))
+
+    def eval_run(self, use_bias=False, offset=0.0):
+        return self.metrics_from_sums(self.eval_sums(use_bias, offset))

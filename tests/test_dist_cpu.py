@@ -181,3 +181,84 @@ def test_two_rank_sgd_epochs_follow_the_partitioned_definition(chunks, tmp_path)
     for p in parts:
         assert np.max(np.abs(p["m_beta"] - st["m_beta"])) <= 1e-12
         assert np.max(np.abs(p["m_item_bias"] - st["m_item_bias"])) <= 1e-12
+
+
+# ---- the model classes' sharded fit, host logic only (no GPU): OracleContext stands in for pmf_hip.Context -----
+def _fit_problem():
+    import pandas as pd
+    from helpers import skewed_problem
+    u, i, x = skewed_problem(5, 300, 50, 5000, rating_kind="count")
+    rng = np.random.default_rng(0)
+    is_val = rng.random(len(u)) < 0.15
+    is_val[0] = False
+    train = pd.DataFrame({"u": u[~is_val], "i": i[~is_val], "rating": x[~is_val]})
+    val = pd.DataFrame({"u": np.append(u[is_val], 305), "i": np.append(i[is_val], 3), "rating": np.append(x[is_val], 4.0)})
+    return train, val
+
+
+def _fit_model(kind, comm):
+    if kind == "hpf":
+        from src.models.hpf_cavi import HPF_CAVI, HPF_CAVI_Config
+        return HPF_CAVI(HPF_CAVI_Config(n_factors=5, a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0,
+                                        max_iter=8, tol=1e-3, verbose=False), dtype="f64", comm=comm), \
+            ("E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_theta", "gamma_b_beta")
+    from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
+    return GaussianMFCAVI(GaussianMFCAVIConfig(n_factors=5, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0,
+                                               max_iter=4, tol=-1.0, verbose=False), dtype="f64", comm=comm), \
+        ("m_theta", "m_beta", "m_user_bias", "m_item_bias")
+
+
+def _run_fit(kind, comm):
+    train, val = _fit_problem()
+    model, keys = _fit_model(kind, comm)
+    if kind == "gauss":
+        gm = float(train["rating"].mean())
+        a, b = train.copy(), val.copy()
+        a["rating"] -= gm; b["rating"] -= gm
+        model.fit(a, val_df=b, global_mean=gm)
+        pred = model.predict(val["u"].to_numpy(), val["i"].to_numpy(), gm)
+    else:
+        model.fit(train, val_df=val)
+        pred = model.predict(val["u"].to_numpy(), val["i"].to_numpy())
+    out = {k: getattr(model, k) for k in keys}
+    out.update(pred=pred, val_rmse=np.array(model.history_["val_rmse"]), iters=model.history_["iterations"])
+    return model, out
+
+
+def _fit_worker(rank, world, port, kind, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PMF_DIST_CHUNKS="3")
+    import torch.distributed as tdist
+    import pmf_hip
+    from oracle_engine import AttachingGlooComm, OracleContext
+    pmf_hip.Context = OracleContext           # the model classes look the context class up at run time
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    model, out = _run_fit(kind, AttachingGlooComm() if world > 1 else None)
+    if kind == "gauss" and world > 1:
+        lo, hi = model.user_range
+        assert model.V_theta.shape[0] == hi - lo                  # local rows only; the gather is explicit
+        out["V_theta"] = model.gather_V_theta()
+    np.savez(os.path.join(out_dir, f"w{world}_rank{rank}.npz"), **out)
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["hpf", "gauss"])
+def test_sharded_model_fit_host_logic_over_gloo(kind, tmp_path):
+    """Two gloo ranks run the model classes' user-sharded `fit` (shard_bounds / take_shard, the attached
+    communicator, the all-reduced validation monitor with identical early-stop decisions, the gather of the
+    user side, predict on the full-size context) and must reproduce the one-rank fit."""
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_fit_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    one = np.load(os.path.join(tmp_path, "w1_rank0.npz"))
+    for rank in range(2):
+        d = np.load(os.path.join(tmp_path, f"w2_rank{rank}.npz"))
+        assert int(d["iters"]) == int(one["iters"]) and int(one["iters"]) >= 3
+        np.testing.assert_allclose(d["val_rmse"], one["val_rmse"], rtol=1e-10)
+        for k in one.files:
+            if k not in ("iters", "val_rmse"):
+                np.testing.assert_allclose(d[k], one[k], rtol=1e-9, atol=1e-11, err_msg=k)
+    if kind == "gauss":
+        assert np.load(os.path.join(tmp_path, "w2_rank0.npz"))["V_theta"].shape == (300, 5, 5)

@@ -23,6 +23,8 @@ for w, (cls, kname) in dominant.items():
         for k, v in agg.items():
             per[k][c] = (sum(v) / len(v), len(v))
     for k, d in per.items():
+        if k.startswith("__amd_rocclr") or "rocprim" in k:   # runtime fills / the one-off library sort
+            continue
         f, nf = d.get("FETCH_SIZE", (0.0, 0))
         wv, nw = d.get("WRITE_SIZE", (0.0, 0))
         hbm = (2 * f + wv) * 1024

@@ -82,16 +82,27 @@ __device__ __forceinline__ void tri_rc(int p, int &r, int &c) {
 // (the outer product needs m[r] m[c] for every packed entry), their covariance
 // chunks are loaded as 16/32-byte accesses (2 x CH in flight per lane) and
 // acc += V + m[r] m[c].  The (r, c) of a lane's entries are pass constants.
-template <typename T>
-__global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T> p) {
+template <typename T, int KR>
+__device__ __forceinline__ void solve_from_image(const T *img, T wj, int K, int kpad, T inv_sigma2, T inv_eta2,
+                                                 T *vout, T *mout, int lane);
+
+// KS > 0 (K <= 64): a task that is a whole row keeps its sums in an LDS image and is solved on the spot by the
+// same wavefront (the KS-row register sweep), as in the MFMA kernels -- this is how fp64 contexts (parity mode)
+// stop paying a separate solve launch.
+template <typename T, int KS = 0>
+__global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T> p, T inv_sigma2 = (T)0, T inv_eta2 = (T)0,
+                                                                  T *cov_self = nullptr, T *factor_self = nullptr) {
     constexpr int CH = 4;  // chunks per lane per pass -> 64 * CH * 4 = 1024 packed entries per pass
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;
     if (task_id >= p.n_tasks) return;
     const PmfTask t = load_task_uniform(p.tasks, task_id);
-    T *m0 = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * 2 * p.kpad;
+    const int lds_per_wave = 2 * p.kpad + (KS > 0 ? p.cov_stride : 0);
+    T *m0 = reinterpret_cast<T *>(smem_raw) + (int64_t)wave * lds_per_wave;
     T *m1 = m0 + p.kpad;
+    T *img = m1 + p.kpad;                       // [cov_stride], KS > 0 only
+    const bool solve_here = KS > 0 && t.slot < 0;
     const int32_t *col = p.other + t.start;
     const T *val = p.val + t.start;
     const T b_self = p.bias_self ? p.bias_self[t.row] : (T)0;
@@ -164,8 +175,16 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
 #pragma unroll
                 for (int e = 0; e < PMF_VEC; ++e)
                     if (q * PMF_VEC + e >= p.kp) acc[s].v[e] = (T)0;
-                store4(out_s + (int64_t)q * PMF_VEC, acc[s]);
+                store4((solve_here ? img : out_s) + (int64_t)q * PMF_VEC, acc[s]);
             }
+        }
+    }
+    if constexpr (KS > 0) {
+        if (solve_here) {
+            wave_lds_fence();
+            solve_from_image<T, KS>(img, wacc[0], p.K, p.kpad, inv_sigma2, inv_eta2,
+                                    cov_self + (int64_t)t.row * p.cov_stride, factor_self + (int64_t)t.row * p.kpad, lane);
+            return;
         }
     }
 #pragma unroll
@@ -1435,9 +1454,31 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
                 }
             }
         }
-        if (!fast)
-            hipLaunchKernelGGL((gauss_accum_generic_kernel<T>), grid, dim3(256),
-                               (size_t)4 * 2 * ctx->kpad * sizeof(T), ctx->stream, p);
+        if (!fast) {
+            // fp64 contexts (and fp32 with PMF_GAUSS_GENERIC): K <= 64 rows that are one task are solved in the kernel
+            const bool fuse = !stats && !ctx->gauss_unfused && ctx->K <= 64 && std::is_same<T, double>::value;
+            T *cov = (T *)ctx->arr[side][PMF_ARR_COV], *fac = (T *)ctx->arr[side][PMF_ARR_FACTOR];
+            const T is2 = (T)(1.0 / sigma2), ie2 = (T)(1.0 / eta2);
+            const size_t plain = (size_t)4 * 2 * ctx->kpad * sizeof(T), fused_lds = plain + (size_t)4 * ctx->cov_stride * sizeof(T);
+            *fused = fuse;
+            bool launched = false;
+            if constexpr (std::is_same<T, double>::value) {
+                if (fuse) {
+                    launched = true;
+                    if (ctx->K <= 8)
+                        hipLaunchKernelGGL((gauss_accum_generic_kernel<T, 8>), grid, dim3(256), fused_lds, ctx->stream, p, is2, ie2, cov, fac);
+                    else if (ctx->K <= 16)
+                        hipLaunchKernelGGL((gauss_accum_generic_kernel<T, 16>), grid, dim3(256), fused_lds, ctx->stream, p, is2, ie2, cov, fac);
+                    else if (ctx->K <= 32)
+                        hipLaunchKernelGGL((gauss_accum_generic_kernel<T, 32>), grid, dim3(256), fused_lds, ctx->stream, p, is2, ie2, cov, fac);
+                    else
+                        hipLaunchKernelGGL((gauss_accum_generic_kernel<T, 64>), grid, dim3(256), fused_lds, ctx->stream, p, is2, ie2, cov, fac);
+                }
+            }
+            if (!launched)
+                hipLaunchKernelGGL((gauss_accum_generic_kernel<T, 0>), grid, dim3(256), plain, ctx->stream, p, (T)0, (T)0,
+                                   (T *)nullptr, (T *)nullptr);
+        }
     }
     if (tl.n_split > 0) {
         PmfProfScope prof(ctx, PMF_KERNEL_GAUSS_COMBINE);

@@ -138,3 +138,59 @@ def test_gaussian_full_size_item_side_heaviest_rows(ratings):
         # fp32 sums over up to 1M ratings: relative to the row's scale
         assert np.max(np.abs(V_beta[rr] - V)) <= 2e-3 * np.abs(V).max(), (rr, len(sel))
         assert np.max(np.abs(m_beta[rr] - want)) <= 2e-3 * max(np.abs(want).max(), 1e-3), (rr, len(sel))
+
+
+def test_gaussian_k128_shard_size_item_side_fused_and_sharded_paths():
+    """BASELINE config C4's per-GPU shard (K = 128, 1.25M users x 1M items, 62.5M ratings; 78 GB of device state):
+    one item half-sweep (gaussian_mf_cavi_bias.py:170-201) two ways -- the fused launch
+    (`gauss_accum_mfma128_kernel<17, fused>`) and the multi-GPU path a C4 rank takes (accumulate into the 33.5 GB
+    statistics buffer -> RCCL all-reduce per item chunk -> finalize, here over a one-rank communicator) -- against
+    each other and, on sampled items (the heaviest included), against the NumPy normal equations."""
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_FACTOR, ITEM, USER, dist as pdist
+    from pmf_hip.engine import Context
+    from pmf_hip.synth import synth_ratings
+    U2, I2, N2, K2 = 1_250_000, 1_000_000, 62_500_000, 128
+    u, i, r = synth_ratings(U2, I2, N2, seed=7)
+    x = r - r.mean()
+    rng = np.random.default_rng(3)
+    m_theta = (0.3 * rng.standard_normal((U2, K2))).astype(np.float32).astype(np.float64)
+    b_user = 0.05 * rng.standard_normal(U2)
+    b_item = 0.05 * rng.standard_normal(I2)
+    c_scale = 0.25
+    comm = pdist.Comm(0, 1, 0, Context.comm_unique_id(), "rccl")
+    try:
+        with pmf_hip.Context(U2, I2, K2, dtype="f32") as ctx:
+            ctx.set_ratings(u, i, x)
+            ctx.set_array(USER, ARR_FACTOR, m_theta)
+            ctx.set_array(USER, ARR_BIAS, b_user); ctx.set_array(ITEM, ARR_BIAS, b_item)
+            ctx.set_cov_identity(USER, c_scale)
+            out = []
+            for sharded in (False, True):
+                ctx.set_array(ITEM, ARR_FACTOR, np.zeros((I2, K2)))
+                ctx.set_cov_identity(ITEM, 1.0)
+                if sharded:
+                    comm.attach(ctx)
+                    ctx.set_row_chunks(ITEM, 8)
+                ctx.gauss_factor_sweep(ITEM, 0.3, 0.5)
+                out.append(ctx.get_array(ITEM, ARR_FACTOR))
+            assert ctx.device_bytes() > 100e9          # the statistics buffer of the sharded path is there
+    finally:
+        comm.close()
+    m_fused, m_shard = out
+    # same sums, same solve arithmetic up to the separate-launch solve's order of operations
+    assert np.max(np.abs(m_fused - m_shard)) <= 2e-4 * max(1.0, np.abs(m_fused).max())
+    deg_i = np.bincount(i, minlength=I2)
+    heavy = np.argsort(-deg_i)[:2]
+    rows = np.concatenate([heavy, rng.choice(I2, 6, replace=False)])
+    pos = {int(rr): np.nonzero(i == rr)[0] for rr in rows}      # (no 62.5M-element argsort needed for 8 rows)
+    for rr in rows:
+        sel = pos[int(rr)]
+        if len(sel) == 0:
+            assert not m_fused[rr].any() and not m_shard[rr].any()
+            continue
+        mo = m_theta[u[sel]]
+        P = np.eye(K2) / 0.5 + (len(sel) * c_scale * np.eye(K2) + mo.T @ mo) / 0.3
+        want = np.linalg.solve(P, (mo * (x[sel] - b_item[rr] - b_user[u[sel]])[:, None]).sum(axis=0)) / 0.3
+        for got in (m_fused, m_shard):
+            assert np.max(np.abs(got[rr] - want)) <= 2e-3 * max(np.abs(want).max(), 1e-3), (rr, len(sel))

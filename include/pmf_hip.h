@@ -206,7 +206,8 @@ int pmf_gamma_finalize(pmf_ctx *ctx, int side, const void *stats_dev, double sha
  *     S      = sum_j ( COV_other[o_j] + FACTOR_other[o_j] FACTOR_other[o_j]^T )
  *     COV[r] = inv( I/eta2 + S/sigma2 )
  *     FACTOR[r] = (1/sigma2) COV[r] . sum_j FACTOR_other[o_j] (x_j - BIAS_side[r] - BIAS_other[o_j])
- * Rows without ratings keep their mean and covariance. */
+ * Rows without ratings keep their mean and covariance.  n_factors <= 256 (PMF_ERANGE above; the reference
+ * has no limit, its grids stop at 70); the MFMA kernels cover K <= 128 in fp32, K > 128 and fp64 run generic ones. */
 int pmf_gauss_factor_sweep(pmf_ctx *ctx, int side, double sigma2, double eta2);
 /* Bias half-sweep (gaussian_mf_cavi_bias.py:206-232 users, :237-263 items):
  *     BIAS[r] = var/sigma2 * sum_j (x_j - BIAS_other[o_j] - FACTOR_other[o_j].FACTOR_side[r]),

@@ -74,7 +74,7 @@ __device__ __forceinline__ void tri_rc(int p, int &r, int &c) {
 }
 
 // ---------------------------------------------------------------------------
-// accumulate, generic (any K <= 128, fp32 / fp64): VALU outer products
+// accumulate, generic (any K <= 256, fp32 / fp64): VALU outer products
 // ---------------------------------------------------------------------------
 // One wavefront per task.  The packed range is covered in passes of 64 x CH
 // 4-element chunks (lane owns chunks q = lane + 64 s of the pass); per pass the
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
         out_s = p.dst_s + (int64_t)t.row * p.dst_s_stride;
         out_w = p.dst_w + (int64_t)t.row * p.dst_w_stride;
     }
-    T wacc[2] = {(T)0, (T)0};  // K <= 128: k = lane, lane + 64
+    T wacc[4] = {(T)0, (T)0, (T)0, (T)0};  // K <= 256: k = lane + 64 e
     for (int q0 = 0; q0 < chunks; q0 += 64 * CH) {
         Vec4<T> acc[CH];
         int rc[CH][PMF_VEC];  // r | c << 8 of every entry this lane owns in this pass
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
                 const T r0 = val[j] - b_self - (p.bias_other ? p.bias_other[o0] : (T)0);
                 const T r1 = two ? val[j + 1] - b_self - (p.bias_other ? p.bias_other[o1] : (T)0) : (T)0;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < 4; ++e) {
                     const int k = lane + 64 * e;
                     if (k < p.K) wacc[e] += m0[k] * r0 + m1[k] * r1;
                 }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T>
         }
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < 4; ++e) {
         const int k = lane + 64 * e;
         if (k < p.kpad) out_w[k] = k < p.K ? wacc[e] : (T)0;
     }
@@ -1127,20 +1127,25 @@ __global__ __launch_bounds__(256) void gauss_combine_kernel(GaussParams<T> p) {
 // solve: V = inv(I/eta2 + S/sigma2), m = V w / sigma2
 // ---------------------------------------------------------------------------
 
-// Generic solve for 64 < K <= 128: one block per row, full matrix in LDS.
+// Generic solve for K > 64 (fp64) / K > 128: one block per row, Gauss-Jordan sweep on the full matrix.  The matrix
+// lives in LDS while K (K + 1) + 3 K elements fit the CU's 160 KB (fp32: K <= 200, fp64: K <= 141); beyond that
+// (`scratch` != null) every block keeps it in its own slice of a global scratch buffer -- L2-resident, slow, and
+// only there so that the Gaussian model has no K limit below the context's 256 (the reference has none at all).
 template <typename T>
-__global__ __launch_bounds__(256) void gauss_solve_lds_kernel(SolveParams<T> p) {
+__global__ __launch_bounds__(256) void gauss_solve_lds_kernel(SolveParams<T> p, T *scratch) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int64_t idx = blockIdx.x;
+    const int K = p.K, ld = K + 1;
+    T *lds = reinterpret_cast<T *>(smem_raw);
+    T *A = scratch ? scratch + (int64_t)blockIdx.x * K * ld : lds;   // [K][ld]
+    T *g = scratch ? lds : lds + K * ld;                             // [K] scaling
+    T *prow = g + K;                                                 // [K] scaled pivot row
+    T *pcol = prow + K;                                              // [K] pivot column
+    const int tid = threadIdx.x;
+    for (int64_t idx = blockIdx.x; idx < p.n; idx += gridDim.x) {
     const int row = p.rows ? p.rows[idx] : (int)(p.row0 + idx);
     const T *S = p.src_s + (int64_t)row * p.src_s_stride;
-    if (!p.rows && S[0] == (T)0) return;
-    const int K = p.K, ld = K + 1;
-    T *A = reinterpret_cast<T *>(smem_raw);  // [K][ld]
-    T *g = A + K * ld;                       // [K] scaling
-    T *prow = g + K;                         // [K] scaled pivot row
-    T *pcol = prow + K;                      // [K] pivot column
-    const int tid = threadIdx.x;
+    if (!p.rows && S[0] == (T)0) continue;   // uniform for the block
+    __syncthreads();
     for (int e = tid; e < K * K; e += 256) {
         const int i = e / K, j = e % K;
         const int lo = i < j ? i : j, hi = i < j ? j : i;
@@ -1189,6 +1194,7 @@ __global__ __launch_bounds__(256) void gauss_solve_lds_kernel(SolveParams<T> p) 
         if (i < K)
             for (int jj = 0; jj < K; ++jj) m = fma(A[i * ld + jj], prow[jj], m);
         p.factor[(int64_t)row * p.kpad + i] = m * p.inv_sigma2;
+    }
     }
 }
 
@@ -1308,7 +1314,7 @@ __global__ void gauss_bias_finalize_all_kernel(BiasParams<T> p) {
 #define GAUSS_PROLOGUE(fn)                                                                              \
     PMF_REQUIRE(ctx != nullptr, PMF_EINVAL, fn ": null context");                                       \
     PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, fn ": bad side %d", side);  \
-    PMF_REQUIRE(ctx->K <= 128, PMF_ERANGE, fn ": the Gaussian path supports n_factors <= 128 (got %d)", ctx->K); \
+    PMF_REQUIRE(ctx->K <= 256, PMF_ERANGE, fn ": the Gaussian path supports n_factors <= 256 (got %d)", ctx->K); \
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
 
 static bool use_bias(const pmf_ctx *ctx) {
@@ -1442,7 +1448,10 @@ static int run_factor_accumulate(pmf_ctx *ctx, int side, void *stats, double sig
                 *fused = fuse;
                 const float is2 = (float)(1.0 / sigma2), ie2 = (float)(1.0 / eta2);
                 float *cov = (float *)ctx->arr[side][PMF_ARR_COV], *fac = (float *)ctx->arr[side][PMF_ARR_FACTOR];
-                if (ctx->K <= 64) {
+                if (ctx->K > 128) {
+                    fast = false;       // 128 < K <= 256: the generic kernels (no reference configuration is this large)
+                    *fused = false;
+                } else if (ctx->K <= 64) {
                     launch_accum_mfma(ctx, p, grid, fuse, is2, ie2, cov, fac);
                 } else {  // 64 < K <= 128: one 128-thread block (two wavefronts) per task
                     const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
@@ -1537,7 +1546,7 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (ctx->K <= 16) launch_solve_reg<T, 16>(ctx, sp);
     else if (ctx->K <= 32) launch_solve_reg<T, 32>(ctx, sp);
     else if (ctx->K <= 64) launch_solve_reg<T, 64>(ctx, sp);
-    else if (std::is_same<T, float>::value && !ctx->gauss_lds_solve) {
+    else if (std::is_same<T, float>::value && !ctx->gauss_lds_solve && ctx->K <= 128) {
         if constexpr (std::is_same<T, float>::value) {
             const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
             if (ctx->K == 128)
@@ -1549,14 +1558,22 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
         }
     } else {
         const int K = ctx->K;
-        size_t smem = ((size_t)K * (K + 1) + 3 * K) * sizeof(T);
+        const size_t mat = (size_t)K * (K + 1) * sizeof(T), vecs = (size_t)3 * K * sizeof(T);
+        const bool in_lds = mat + vecs <= (size_t)160 * 1024;
+        const unsigned blocks = (unsigned)std::min<int64_t>(sp.n, in_lds ? sp.n : 2048);
+        T *scratch = nullptr;
+        if (!in_lds) {   // one matrix per resident block in global scratch (<= 2048 x 264 KB)
+            if ((rc = pmf_ensure_scratch(ctx, (size_t)blocks * mat))) return rc;
+            scratch = (T *)ctx->d_scratch;
+        }
+        const size_t smem = in_lds ? mat + vecs : vecs;
         hipError_t e = hipFuncSetAttribute((const void *)gauss_solve_lds_kernel<T>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             pmf_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", smem, hipGetErrorString(e));
             return PMF_EHIP;
         }
-        hipLaunchKernelGGL((gauss_solve_lds_kernel<T>), dim3((unsigned)sp.n), dim3(256), smem, ctx->stream, sp);
+        hipLaunchKernelGGL((gauss_solve_lds_kernel<T>), dim3(blocks), dim3(256), smem, ctx->stream, sp, scratch);
     }
     PMF_HIP_CHECK(hipGetLastError());
     return PMF_OK;

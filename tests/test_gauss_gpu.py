@@ -155,3 +155,16 @@ def test_empty_rows_keep_initial_state():
         assert np.array_equal(ctx.get_array(ITEM, ARR_FACTOR)[3], b0[3])
         assert np.array_equal(ctx.get_array(USER, ARR_COV)[7], np.eye(K))
         assert not np.allclose(ctx.get_array(USER, ARR_FACTOR)[8], m0[8])
+
+
+@pytest.mark.parametrize("K,dtype,tol", [(136, "f32", 3e-4), (256, "f32", 6e-4), (150, "f64", 1e-9)])
+def test_gaussian_beyond_128_factors(K, dtype, tol):
+    """The reference has no K limit (its grids stop at 70); the context's limit is 256.  K > 128 runs the generic
+    accumulate kernel and the block-per-row sweep -- matrix in LDS while it fits (fp32 K <= 200, fp64 K <= 141), in a
+    per-block global scratch slice beyond -- against the oracle on a small skewed problem."""
+    got, st = _oracle_vs_device(K, dtype, bias=True, U=400, I=60, N=4500, iters=2)
+    for key in ("m_theta", "m_beta", "m_user_bias", "m_item_bias"):
+        assert max_abs(got[key], st[key]) <= tol, key
+    for key in ("V_theta", "V_beta"):
+        scale = np.abs(st[key]).max(axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(got[key] - st[key]) / scale) <= tol, key

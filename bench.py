@@ -409,7 +409,7 @@ def main():
                 roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of this workload; static)"
             except Exception:
                 pass
-        if dominant == "gamma_sweep" and comm is None:
+        if dominant == "gamma_sweep":
             # The gathered tables live in L2 / Infinity Cache (25.6 MB of item rows, 256 MB of user rows), so HBM
             # does not bound this kernel: its roofline is what the cache hierarchy delivers for this gather
             # pattern, measured live by the kernel's gather-only twin on the same ratings and tables.

@@ -40,14 +40,21 @@ class DeviceModel:
     _uses_bias = False
     _gaussian = False     # Gaussian models exchange [I x (Kp + Kpad)] statistics, the others [I x 2 Kpad]
 
-    def __init__(self, config, dtype=None, device=None, comm=None):
+    def __init__(self, config, dtype=None, device=None, comm=None, presharded=False):
         """`comm`: a `pmf_hip.dist.Comm` (the RCCL communicator inside libpmf_hip.so, one rank
         per GPU; `pmf_hip.dist.init_from_env()`) makes `fit` a user-sharded multi-GPU run: every
         rank passes the SAME frames, keeps the ratings of its user range, item statistics are
         all-reduced once per item half-sweep by the library, and every rank ends with the full
-        factor matrices."""
+        factor matrices.
+
+        `presharded=True` (with `comm`): `fit` is given only THIS RANK's training rows instead -- global
+        user ids, rank r holding a contiguous id range that lies above rank r-1's -- so no rank ever
+        holds the full frame (12 GB per rank at BASELINE config C4); dimensions and the ranges are
+        agreed by small all-reduces.  Either way the initial state is drawn with the reference's RNG
+        sequence and a rank keeps only its own users' rows of it."""
         self.config = config
         self._comm = comm if (comm is not None and comm.world > 1) else None
+        self._presharded = bool(presharded) and self._comm is not None
         self._bounds = None
         self.n_users = None
         self.n_items = None
@@ -64,10 +71,54 @@ class DeviceModel:
 
     # ---- dimensions (hpf_cavi.py:60-64) ----------------------------------
     def _infer_dimensions(self, train_df):
-        self.n_users = int(train_df["u"].max()) + 1
-        self.n_items = int(train_df["i"].max()) + 1
+        self.n_users = int(train_df["u"].max()) + 1 if len(train_df) else 0
+        self.n_items = int(train_df["i"].max()) + 1 if len(train_df) else 0
+        if self._presharded:   # every rank sees its own rows only: the dimensions are the maxima over the ranks
+            dims = self._comm.all_reduce_host([float(self.n_users), float(self.n_items)], op="max")
+            self.n_users, self.n_items = int(dims[0]), int(dims[1])
         if self.config.verbose:
             print(f"Inferred n_users={self.n_users}, n_items={self.n_items}")
+        self._plan_shards(train_df)
+
+    def _plan_shards(self, train_df):
+        """User ranges of a sharded fit, known before the initial state is drawn."""
+        self._bounds = None
+        if self._comm is None:
+            return
+        from pmf_hip import dist as pdist
+        comm = self._comm
+        if not self._presharded:
+            self._bounds = pdist.shard_bounds(train_df["u"].to_numpy(dtype=int), self.n_users, comm.world)
+            return
+        u = train_df["u"].to_numpy(dtype=int)
+        top = np.zeros(comm.world)
+        low = np.full(comm.world, 0.0)
+        top[comm.rank] = float(u.max()) + 1 if len(u) else 0.0
+        low[comm.rank] = float(u.min()) if len(u) else 0.0
+        top, low = comm.all_reduce_host(top), comm.all_reduce_host(low)
+        top = np.maximum.accumulate(top)                    # a rank without rows owns an empty range
+        top[-1] = self.n_users
+        bounds = np.concatenate([[0.0], top]).astype(np.int64)
+        for r in range(comm.world):
+            if low[r] < bounds[r] and top[r] > bounds[r]:
+                raise ValueError(f"presharded fit: rank {r}'s user ids start at {int(low[r])}, inside rank {r - 1}'s range "
+                                 f"(< {int(bounds[r])}); every rank must hold a contiguous user-id range above the previous rank's")
+        self._bounds = bounds
+
+    def _user_rows(self, draw):
+        """`draw(n)` -> the next n rows of a user-side initial array from the model's RNG.  Unsharded: all
+        rows.  Sharded: the SAME stream is consumed (so every rank's state is the reference's), in blocks,
+        and only this rank's rows are kept -- no rank materialises a full user-side array."""
+        if self._comm is None:
+            return draw(self.n_users)
+        lo, hi = int(self._bounds[self._comm.rank]), int(self._bounds[self._comm.rank + 1])
+        block = 1 << 18
+        for at in range(0, lo, block):
+            draw(min(block, lo - at))
+        mine = draw(hi - lo)
+        for at in range(hi, self.n_users, block):
+            draw(min(block, self.n_users - at))
+        return mine
 
     def _open_context(self, u, i, x):
         if self._ctx is not None:
@@ -75,9 +126,12 @@ class DeviceModel:
         n_local = self.n_users
         from pmf_hip import dist as pdist
         if self._comm is not None:
-            self._bounds = pdist.shard_bounds(u, self.n_users, self._comm.world)
-            u, i, x = pdist.take_shard(u, i, x, self._bounds, self._comm.rank)
-            n_local = int(self._bounds[self._comm.rank + 1] - self._bounds[self._comm.rank])
+            lo, hi = int(self._bounds[self._comm.rank]), int(self._bounds[self._comm.rank + 1])
+            if self._presharded:
+                u = np.asarray(u) - lo              # the frame IS the shard: ids become local to the range
+            else:
+                u, i, x = pdist.take_shard(u, i, x, self._bounds, self._comm.rank)
+            n_local = hi - lo
         self._ctx = pmf_hip.Context(n_local, self.n_items, self.config.n_factors,
                                     dtype=self._dtype, device=self._device)
         if self._comm is not None:
@@ -116,12 +170,15 @@ class DeviceModel:
         self._graph.launch()
 
     # ---- multi-GPU helpers --------------------------------------------------
-    def _mine(self, full_user_array):
-        """This rank's rows of a full user-side array (the whole array when not sharded)."""
+    def _mine(self, user_array):
+        """This rank's rows of a user-side array: arrays made by `_user_rows` (or any array that already has
+        this rank's row count) pass through, full-size ones are sliced."""
         if self._comm is None:
-            return full_user_array
+            return user_array
         lo, hi = int(self._bounds[self._comm.rank]), int(self._bounds[self._comm.rank + 1])
-        return full_user_array[lo:hi]
+        if len(user_array) == hi - lo and hi - lo != self.n_users:
+            return user_array
+        return user_array[lo:hi]
 
     def _user_array(self, array_id, ctx=None):
         """A user-side state array for ALL users on the host: this context's rows, or -- after a
@@ -194,6 +251,16 @@ class DeviceModel:
         from pmf_hip import MAX_LABELS
         comm, ctx = self._comm, self._ctx
         labels = np.unique(y)
+        if self._presharded:
+            # every rank holds its own validation rows: the label set of metrics.macro_mae is their union
+            slots = np.zeros(comm.world * (MAX_LABELS + 1))
+            base = comm.rank * (MAX_LABELS + 1)
+            slots[base] = len(labels)
+            slots[base + 1:base + 1 + min(len(labels), MAX_LABELS)] = labels[:MAX_LABELS]
+            slots = comm.all_reduce_host(slots).reshape(comm.world, MAX_LABELS + 1)
+            if (slots[:, 0] > MAX_LABELS).any():
+                raise NotImplementedError("sharded validation supports at most %d distinct ratings" % MAX_LABELS)
+            labels = np.unique(np.concatenate([row[1:1 + int(row[0])] for row in slots]))
         if len(labels) > MAX_LABELS:
             raise NotImplementedError("sharded validation supports at most %d distinct ratings" % MAX_LABELS)
         lo, hi = int(self._bounds[comm.rank]), int(self._bounds[comm.rank + 1])

@@ -12,8 +12,8 @@ from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, dist as pdist
 
 
 class GaussianHost(DeviceModel):
-    def __init__(self, config, dtype=None, device=None, comm=None):
-        super().__init__(config, dtype, device, comm)
+    def __init__(self, config, dtype=None, device=None, comm=None, presharded=False):
+        super().__init__(config, dtype, device, comm, presharded)
         self.m_theta = self.m_beta = None
         self._V_theta = self._V_beta = None
         self.global_mean = 0.0
@@ -68,10 +68,10 @@ class GaussianHost(DeviceModel):
         """Reference draw order (gaussian_mf_cavi_bias.py:52-67): user means, item means."""
         K = self.config.n_factors
         rng = np.random.default_rng(self.config.random_state)
-        self.m_theta = 0.1 * rng.standard_normal((self.n_users, K))
+        self.m_theta = 0.1 * self._user_rows(lambda n: rng.standard_normal((n, K)))
         self.m_beta = 0.1 * rng.standard_normal((self.n_items, K))
         if self._uses_bias:
-            self.m_user_bias = np.zeros(self.n_users)
+            self.m_user_bias = np.zeros(len(self.m_theta))
             self.m_item_bias = np.zeros(self.n_items)
         self._V_theta = self._V_beta = None
 

@@ -25,5 +25,5 @@ class GaussianMFCAVI(GaussianHost):
     _uses_bias = False
     _gaussian = True
 
-    def __init__(self, config: GaussianMFCAVIConfig, dtype=None, device=None, comm=None):
-        super().__init__(config, dtype, device, comm)
+    def __init__(self, config: GaussianMFCAVIConfig, dtype=None, device=None, comm=None, presharded=False):
+        super().__init__(config, dtype, device, comm, presharded)

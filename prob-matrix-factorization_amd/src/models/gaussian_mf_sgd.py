@@ -37,8 +37,8 @@ class GaussianMFSGD(GaussianHost):
     _gaussian = False            # exchanged item statistics are [I x (Kpad + 4)], not covariances
     _iteration_label = "SGD epoch"
 
-    def __init__(self, config: GaussianMFSGDConfig, dtype=None, device=None, comm=None):
-        super().__init__(config, dtype, device, comm)
+    def __init__(self, config: GaussianMFSGDConfig, dtype=None, device=None, comm=None, presharded=False):
+        super().__init__(config, dtype, device, comm, presharded)
 
     V_theta = property(lambda self: None, lambda self, value: None)
     V_beta = property(lambda self: None, lambda self, value: None)

@@ -34,8 +34,8 @@ class HPF_CAVI(DeviceModel):
     """x_ui ~ Poisson(theta_u . beta_i); theta_uk ~ Gamma(a, xi_u), xi_u ~ Gamma(a', b');
     beta_ik ~ Gamma(c, eta_i), eta_i ~ Gamma(c', d')."""
 
-    def __init__(self, config: HPF_CAVI_Config, dtype=None, device=None, comm=None):
-        super().__init__(config, dtype, device, comm)
+    def __init__(self, config: HPF_CAVI_Config, dtype=None, device=None, comm=None, presharded=False):
+        super().__init__(config, dtype, device, comm, presharded)
         self.gamma_a_theta = self.gamma_b_theta = None
         self.gamma_a_beta = self.gamma_b_beta = None
         self.gamma_a_xi = self.gamma_b_xi = None
@@ -47,13 +47,15 @@ class HPF_CAVI(DeviceModel):
         cfg = self.config
         K, N, M = cfg.n_factors, self.n_users, self.n_items
         rng = np.random.default_rng(cfg.random_state)
-        noise = [rng.gamma(1.0, 0.1, size=shape) for shape in ((N, K), (N, K), (M, K), (M, K))]
+        users = lambda n: rng.gamma(1.0, 0.1, size=(n, K))      # (a sharded fit keeps this rank's rows only)
+        noise = [self._user_rows(users), self._user_rows(users), rng.gamma(1.0, 0.1, size=(M, K)),
+                 rng.gamma(1.0, 0.1, size=(M, K))]
         self.gamma_a_theta = cfg.a + noise[0]
         self.gamma_b_theta = cfg.b_prime + noise[1]
         self.gamma_a_beta = cfg.c + noise[2]
         self.gamma_b_beta = cfg.d_prime + noise[3]
         self.gamma_a_xi = cfg.a_prime + K * cfg.a
-        self.gamma_b_xi = cfg.b_prime * np.ones(N)
+        self.gamma_b_xi = cfg.b_prime * np.ones(len(noise[0]))
         self.gamma_a_eta = cfg.c_prime + K * cfg.c
         self.gamma_b_eta = cfg.d_prime * np.ones(M)
         self._update_expectations()

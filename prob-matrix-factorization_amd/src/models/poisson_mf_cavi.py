@@ -29,8 +29,8 @@ class PoissonMFCAVIConfig:
 class PoissonMFCAVI(DeviceModel):
     """x_ij ~ Poisson(theta_i . beta_j), theta, beta ~ Gamma(a0, b0)."""
 
-    def __init__(self, config: PoissonMFCAVIConfig, dtype=None, device=None, comm=None):
-        super().__init__(config, dtype, device, comm)
+    def __init__(self, config: PoissonMFCAVIConfig, dtype=None, device=None, comm=None, presharded=False):
+        super().__init__(config, dtype, device, comm, presharded)
         self.a_theta = self.b_theta = self.a_beta = self.b_beta = None
         self.E_theta = self.E_beta = None
 
@@ -38,9 +38,9 @@ class PoissonMFCAVI(DeviceModel):
         """Reference draw order (poisson_mf_cavi.py:50-71): user shapes, item shapes."""
         cfg = self.config
         rng = np.random.default_rng(cfg.random_state)
-        self.a_theta = cfg.a0 + rng.gamma(1.0, 0.1, size=(self.n_users, cfg.n_factors))
+        self.a_theta = cfg.a0 + self._user_rows(lambda n: rng.gamma(1.0, 0.1, size=(n, cfg.n_factors)))
         self.a_beta = cfg.a0 + rng.gamma(1.0, 0.1, size=(self.n_items, cfg.n_factors))
-        self.b_theta = np.full((self.n_users, cfg.n_factors), float(cfg.b0))
+        self.b_theta = np.full(self.a_theta.shape, float(cfg.b0))
         self.b_beta = np.full((self.n_items, cfg.n_factors), float(cfg.b0))
         self.E_theta = self.a_theta / self.b_theta
         self.E_beta = self.a_beta / self.b_beta

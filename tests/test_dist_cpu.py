@@ -208,24 +208,32 @@ def _fit_model(kind, comm):
         ("m_theta", "m_beta", "m_user_bias", "m_item_bias")
 
 
-def _run_fit(kind, comm):
+def _run_fit(kind, comm, presharded=False):
     train, val = _fit_problem()
     model, keys = _fit_model(kind, comm)
+    gm = float(train["rating"].mean())
+    full_val = val
+    if presharded:      # hand this rank only its own rows (global user ids)
+        from pmf_hip import dist as pdist
+        b = pdist.shard_bounds(train["u"].to_numpy(), int(train["u"].max()) + 1, comm.world)
+        lo, hi = int(b[comm.rank]), int(b[comm.rank + 1])
+        train = train[(train["u"] >= lo) & (train["u"] < hi)]
+        val = val[(val["u"] >= lo) & ((val["u"] < hi) | (comm.rank == comm.world - 1))]
+        model = type(model)(model.config, dtype="f64", comm=comm, presharded=True)
     if kind == "gauss":
-        gm = float(train["rating"].mean())
         a, b = train.copy(), val.copy()
         a["rating"] -= gm; b["rating"] -= gm
         model.fit(a, val_df=b, global_mean=gm)
-        pred = model.predict(val["u"].to_numpy(), val["i"].to_numpy(), gm)
+        pred = model.predict(full_val["u"].to_numpy(), full_val["i"].to_numpy(), gm)
     else:
         model.fit(train, val_df=val)
-        pred = model.predict(val["u"].to_numpy(), val["i"].to_numpy())
+        pred = model.predict(full_val["u"].to_numpy(), full_val["i"].to_numpy())
     out = {k: getattr(model, k) for k in keys}
     out.update(pred=pred, val_rmse=np.array(model.history_["val_rmse"]), iters=model.history_["iterations"])
     return model, out
 
 
-def _fit_worker(rank, world, port, kind, out_dir):
+def _fit_worker(rank, world, port, kind, out_dir, presharded=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       PMF_DIST_CHUNKS="3")
@@ -234,12 +242,12 @@ def _fit_worker(rank, world, port, kind, out_dir):
     from oracle_engine import AttachingGlooComm, OracleContext
     pmf_hip.Context = OracleContext           # the model classes look the context class up at run time
     tdist.init_process_group("gloo", rank=rank, world_size=world)
-    model, out = _run_fit(kind, AttachingGlooComm() if world > 1 else None)
+    model, out = _run_fit(kind, AttachingGlooComm() if world > 1 else None, presharded and world > 1)
     if kind == "gauss" and world > 1:
         lo, hi = model.user_range
         assert model.V_theta.shape[0] == hi - lo                  # local rows only; the gather is explicit
         out["V_theta"] = model.gather_V_theta()
-    np.savez(os.path.join(out_dir, f"w{world}_rank{rank}.npz"), **out)
+    np.savez(os.path.join(out_dir, f"w{world}{'p' if presharded else ''}_rank{rank}.npz"), **out)
     tdist.barrier()
     tdist.destroy_process_group()
 
@@ -250,11 +258,11 @@ def test_sharded_model_fit_host_logic_over_gloo(kind, tmp_path):
     communicator, the all-reduced validation monitor with identical early-stop decisions, the gather of the
     user side, predict on the full-size context) and must reproduce the one-rank fit."""
     import torch.multiprocessing as mp
-    for world in (1, 2):
-        mp.spawn(_fit_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    for world, pre in ((1, False), (2, False), (2, True)):
+        mp.spawn(_fit_worker, args=(world, _free_port(), kind, str(tmp_path), pre), nprocs=world, join=True)
     one = np.load(os.path.join(tmp_path, "w1_rank0.npz"))
-    for rank in range(2):
-        d = np.load(os.path.join(tmp_path, f"w2_rank{rank}.npz"))
+    for rank, tag in ((0, "w2"), (1, "w2"), (0, "w2p"), (1, "w2p")):     # full frames on every rank / presharded frames
+        d = np.load(os.path.join(tmp_path, f"{tag}_rank{rank}.npz"))
         assert int(d["iters"]) == int(one["iters"]) and int(one["iters"]) >= 3
         np.testing.assert_allclose(d["val_rmse"], one["val_rmse"], rtol=1e-10)
         for k in one.files:

@@ -39,7 +39,10 @@ def _data():
     return train, val
 
 
-def _build(kind, comm=None):
+def _build(kind, comm=None, presharded=False):
+    if presharded:
+        model, keys = _build(kind, comm)
+        return type(model)(model.config, dtype="f64", comm=comm, presharded=True), keys
     if kind == "hpf":
         from src.models.hpf_cavi import HPF_CAVI, HPF_CAVI_Config
         return HPF_CAVI(HPF_CAVI_Config(n_factors=12, a=0.3, a_prime=5.0, b_prime=5.0, c=0.3, c_prime=5.0, d_prime=5.0,
@@ -60,9 +63,9 @@ def _build(kind, comm=None):
         ("m_theta", "m_beta", "m_user_bias", "m_item_bias")
 
 
-def _fit(kind, model, train, val):
+def _fit(kind, model, train, val, gm=None):
     if kind in ("gauss", "sgd"):
-        gm = float(train["rating"].mean())
+        gm = float(train["rating"].mean()) if gm is None else gm     # (presharded ranks are given the global mean)
         a, b = train.copy(), val.copy()
         a["rating"] -= gm; b["rating"] -= gm
         model.fit(a, val_df=b, global_mean=gm)
@@ -86,8 +89,21 @@ def _worker(rank, world, port, kind, out_dir):
     comm = pdist.init_from_env(device=0)
     assert comm.world == world and comm.rank == rank and comm.transport == "hostshm"
     train, val = _data()
-    model, keys = _build(kind, comm=comm)
-    pred = _fit(kind, model, train, val)
+    pre = kind.endswith("_pre")
+    kind = kind[:-4] if pre else kind
+    gm_all = float(train["rating"].mean())
+    if pre:
+        # this rank is handed ONLY its own rows (global user ids): no rank holds the full frames
+        b = pdist.shard_bounds(train["u"].to_numpy(), int(train["u"].max()) + 1, world)
+        lo, hi = int(b[rank]), int(b[rank + 1])
+        full_val = val
+        train = train[(train["u"] >= lo) & (train["u"] < hi)]
+        val = val[(val["u"] >= lo) & ((val["u"] < hi) | (rank == world - 1))]
+    model, keys = _build(kind, comm=comm, presharded=pre)
+    pred = _fit(kind, model, train, val, gm_all)
+    if pre:   # predict works on every rank for ALL pairs afterwards
+        pred = (model.predict(full_val["u"].to_numpy(), full_val["i"].to_numpy(), gm_all) if kind in ("gauss", "sgd")
+                else model.predict(full_val["u"].to_numpy(), full_val["i"].to_numpy()))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pred=pred, val_rmse=np.array(model.history_["val_rmse"]),
              iters=model.history_["iterations"], **{k: getattr(model, k) for k in keys})
     if kind == "gauss":
@@ -119,12 +135,14 @@ def _spawn(kind, out_dir, world=2):
     assert [p.exitcode for p in procs] == [0] * world
 
 
-@pytest.mark.parametrize("kind", ["hpf", "poisson", "gauss"])
+@pytest.mark.parametrize("kind", ["hpf", "poisson", "gauss", "hpf_pre", "gauss_pre"])
 def test_two_rank_fit_matches_single_process(kind, tmp_path):
+    """`*_pre`: the presharded form -- every rank is given only its own training / validation rows."""
     train, val = _data()
-    model, keys = _build(kind)
-    pred = _fit(kind, model, train, val)
+    model, keys = _build(kind[:-4] if kind.endswith("_pre") else kind)
+    pred = _fit(kind[:-4] if kind.endswith("_pre") else kind, model, train, val)
     _spawn(kind, str(tmp_path))
+    kind = kind[:-4] if kind.endswith("_pre") else kind
     for rank in range(2):
         d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         assert int(d["iters"]) == model.history_["iterations"]

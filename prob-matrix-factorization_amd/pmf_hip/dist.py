@@ -258,15 +258,20 @@ def gaussian_sgd_iteration(engine, comm, stats_item, lr, sigma2, eta_theta2, eta
 
 
 def default_item_chunks(world, message_bytes=0):
-    """Item row chunks of a sharded run.  PMF_DIST_CHUNKS if set; else slices of about 256 MB,
-    at least 4 (so that at most a quarter of the all-reduce is exposed) and at most 32, but never
-    below 4 MB per slice (latency-bound collectives).  1 = no pipelining."""
+    """Item row chunks of a sharded run.  PMF_DIST_CHUNKS if set; else slices of about 256 MB, at most 32; at least 4
+    for messages of 64 MB and more (at most a quarter of the all-reduce is then exposed), 2 for smaller ones (every
+    extra chunk costs ~0.1 ms of launch tails at the C3 size -- tools/probe_comm_single.py -- which a 51 MB message
+    cannot win back), 1 below 8 MB (latency-bound collectives).  1 = no pipelining."""
     if world <= 1:
         return 1
     if "PMF_DIST_CHUNKS" in os.environ:
         return max(1, int(os.environ["PMF_DIST_CHUNKS"]))
-    n = min(max(int(message_bytes) // (256 << 20), 4), 32)
-    return max(1, min(n, max(1, int(message_bytes) // (4 << 20)))) if message_bytes else 4
+    if not message_bytes:
+        return 4
+    b = int(message_bytes)
+    if b < (8 << 20):
+        return 1
+    return min(max(b // (256 << 20), 4 if b >= (64 << 20) else 2), 32)
 
 
 def item_message_bytes(ctx, gaussian):

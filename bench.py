@@ -148,6 +148,70 @@ def blas_threads():
         return 1
 
 
+def cpu_baseline_c1(device=0):
+    """BASELINE configs[0] IN FULL -- the reference's own CPU-runnable case (10k x 2k, 200k ratings, K = 16): one
+    iteration of the oracle's per-row loop for the three CAVI models on the host, and the engine's time per iteration
+    on the same ratings (reference on the 8-core build container: 0.91 / 0.29 / 0.30 s per iteration)."""
+    from oracle import cavi_oracle as orc
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_PRIOR_RATE, ITEM, USER
+    from pmf_hip.synth import BASE_SEED, synth_ratings
+    U, I, N, K = 10_000, 2_000, 200_000, 16
+    u, i, r = synth_ratings(U, I, N, seed=BASE_SEED)
+    u64, i64 = u.astype(np.int64), i.astype(np.int64)
+    idx = (orc.group_positions(u64, U), orc.group_positions(i64, I))
+    out = {"sample": f"configs[0] in full: {U}x{I}, {N} ratings, K={K}, one iteration each"}
+    for name in ("gaussian_bias", "poisson", "hpf"):
+        if name == "gaussian_bias":
+            x = r - float(r.mean())
+            st = orc.init_gaussian(U, I, K, 0, True)
+        elif name == "poisson":
+            x = r
+            st = orc.init_poisson(U, I, K, 0.1, 0.5, 0)
+        else:
+            x = r + 1.0
+            st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, 0)
+        with pmf_hip.Context(U, I, K, dtype="f32", device=device) as ctx:
+            ctx.set_ratings(u, i, x)
+            if name == "gaussian_bias":
+                ctx.set_array(USER, ARR_FACTOR, st["m_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["m_beta"])
+                ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
+                ctx.set_array(USER, ARR_BIAS, st["m_user_bias"]); ctx.set_array(ITEM, ARR_BIAS, st["m_item_bias"])
+
+                def step():
+                    ctx.gauss_factor_sweep(USER, 0.3, 0.5); ctx.gauss_factor_sweep(ITEM, 0.3, 0.5)
+                    ctx.gauss_bias_sweep(USER, 0.3, 1.0); ctx.gauss_bias_sweep(ITEM, 0.3, 1.0)
+            else:
+                ctx.set_array(USER, ARR_FACTOR, st["E_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["E_beta"])
+                hier = name == "hpf"
+                if hier:
+                    ctx.set_array(USER, ARR_PRIOR_RATE, st["E_xi"]); ctx.set_array(ITEM, ARR_PRIOR_RATE, st["E_eta"])
+                pu = (0.3, 0.0, True, st["gamma_a_xi"], 5.0) if hier else (0.1, 0.5)
+                pi = (0.3, 0.0, True, st["gamma_a_eta"], 5.0) if hier else (0.1, 0.5)
+
+                def step():
+                    ctx.gamma_sweep(USER, *pu); ctx.gamma_sweep(ITEM, *pi)
+            for _ in range(5):
+                step()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                step()
+            ctx.sync()
+            gpu_s = (time.perf_counter() - t0) / 100
+        t0 = time.perf_counter()
+        if name == "gaussian_bias":
+            orc.gaussian_iteration(st, idx, u64, i64, x, 0.3, 0.5, 0.5, 1.0)
+        elif name == "poisson":
+            orc.poisson_iteration(st, idx, u64, i64, x, 0.1, 0.5)
+        else:
+            orc.hpf_iteration(st, idx, u64, i64, x, 0.3, 5.0, 0.3, 5.0)
+        cpu_s = time.perf_counter() - t0
+        out[name] = {"cpu_ratings_per_s": N / cpu_s, "cpu_s_per_iteration": cpu_s, "gpu_us_per_iteration": gpu_s * 1e6,
+                     "gpu_ratings_per_s": N / gpu_s}
+    return out
+
+
 def cpu_baseline(workload, K, hp, device=0):
     """The CPU oracle's per-row loop (the reference's loop structure) on a bounded sample of
     the same generator: ~10-30 s of CPU work with NumPy's default BLAS threading (`cores` = the
@@ -212,6 +276,8 @@ def cpu_baseline(workload, K, hp, device=0):
                      f"(same generator), {dt:.1f} s, default BLAS threading",
            "cpu_model": model, "logical_cores": logical,
            "val_rmse_cpu": rm_cpu, "val_rmse_gpu_f32": rm_gpu, "val_rmse_abs_diff": abs(rm_cpu - rm_gpu)}
+    if gauss and K == 64:
+        out["c1_full"] = cpu_baseline_c1(device)
     if not gauss:
         # "best-effort CPU" (BASELINE.md section 3): the same iteration as whole-array NumPy
         # (gather + segment sums, no per-row interpreter loop), a quarter of the sample

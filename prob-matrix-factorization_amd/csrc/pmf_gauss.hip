@@ -1353,6 +1353,12 @@ static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 gr
             case 4: launch_accum_mfma_nt<64, 4, 48>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
             default: launch_accum_mfma_nt<64, 5, 48>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
         }
+    } else if (ctx->K <= 56) {   // Kp <= 1596: 5..7 chunk columns; a 56-row sweep (K = 50 is in the reference's grid)
+        switch (nt) {
+            case 5: launch_accum_mfma_nt<64, 5, 56>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            case 6: launch_accum_mfma_nt<64, 6, 56>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+            default: launch_accum_mfma_nt<64, 7, 56>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;
+        }
     } else {
         switch (nt) {
             case 3: launch_accum_mfma_nt<64, 3>(ctx, p, grid, fuse, is2, ie2, cov, fac); break;

@@ -1383,6 +1383,12 @@ static void launch_accum_mfma128(pmf_ctx *ctx, const GaussParams<float> &p, dim3
                 return;
             }
         }
+        if constexpr (NT == 9) {
+            if (ctx->K <= 80) {   // an 80-row sweep (K = 70 is in the reference's grid)
+                hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 40>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+                return;
+            }
+        }
         if constexpr (NT <= 13) {
             if (ctx->K <= 96) {
                 hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 48>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
@@ -1557,6 +1563,8 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
             const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
             if (ctx->K == 128)
                 hipLaunchKernelGGL((gauss_solve_pair_kernel<64, true>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
+            else if (ctx->K <= 80)
+                hipLaunchKernelGGL((gauss_solve_pair_kernel<40, false>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
             else if (ctx->K <= 96)
                 hipLaunchKernelGGL((gauss_solve_pair_kernel<48, false>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
             else

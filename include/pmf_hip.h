@@ -234,8 +234,8 @@ int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, doubl
  * side = PMF_SIDE_ITEM) runs inside the library as
  *     accumulate raw per-item sums over this rank's ratings  ->  all-reduce (sum)  ->  finalize
  * on a library-owned statistics buffer, pipelined over the item row chunks of pmf_ctx_set_row_chunks:
- * the all-reduce of chunk c runs on a second, high-priority HIP stream (ordered against the compute
- * stream by events, never by the host) while chunk c+1 is accumulated.  Per-row arithmetic is that of
+ * the all-reduce of chunk c runs on a second, high-priority HIP stream and its finalisation on a third
+ * (ordered against the compute stream by events, never by the host) while chunk c+1 is accumulated.  Per-row arithmetic is that of
  * the accumulate / finalize pair, so results do not depend on the chunking, and every rank ends the
  * half-sweep with bit-identical item state.  USER-side half-sweeps stay local.  The iteration order a
  * caller issues is unchanged (gaussian_mf_cavi_bias.py:129-263, hpf_cavi.py:121-193).

@@ -66,7 +66,8 @@ struct PmfComm {
     int transport = PMF_TRANSPORT_RCCL;
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;             // the collectives' stream
-    std::vector<hipEvent_t> ev_ready, ev_done;  // per row chunk: statistics ready / all-reduced
+    hipStream_t fin_stream = nullptr;         // finalize(c) runs here, beside the accumulation of later chunks
+    std::vector<hipEvent_t> ev_ready, ev_done, ev_fin;  // per row chunk: statistics ready / all-reduced / finalized
     void *d_small = nullptr;                  // kSmallBytes, host-value collectives
     void *h_small = nullptr;                  // pinned twin
     // HOSTSHM
@@ -244,6 +245,11 @@ void comm_free(PmfComm *cm) {
     if (cm->nccl) (void)ncclCommDestroy(cm->nccl);
     for (auto &e : cm->ev_ready) (void)hipEventDestroy(e);
     for (auto &e : cm->ev_done) (void)hipEventDestroy(e);
+    for (auto &e : cm->ev_fin) (void)hipEventDestroy(e);
+    if (cm->fin_stream) {
+        (void)hipStreamSynchronize(cm->fin_stream);
+        (void)hipStreamDestroy(cm->fin_stream);
+    }
     if (cm->d_small) (void)hipFree(cm->d_small);
     if (cm->h_small) (void)hipHostFree(cm->h_small);
     if (cm->h_result) (void)hipHostFree(cm->h_result);
@@ -277,6 +283,12 @@ int comm_create(pmf_ctx *ctx, int nranks, int rank, const void *unique_id, int t
             rc = PMF_EHIP;
             break;
         }
+        e = hipStreamCreateWithFlags(&cm->fin_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            pmf_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            rc = PMF_EHIP;
+            break;
+        }
         if (hipMalloc(&cm->d_small, kSmallBytes) != hipSuccess ||
             hipHostMalloc(&cm->h_small, kSmallBytes, hipHostMallocDefault) != hipSuccess) {
             pmf_set_error("pmf_comm_init: cannot allocate the collective staging buffers");
@@ -307,17 +319,19 @@ int comm_create(pmf_ctx *ctx, int nranks, int rank, const void *unique_id, int t
 }
 
 int ensure_events(PmfComm *cm, size_t n) {
-    while (cm->ev_ready.size() < n) {
-        hipEvent_t a = nullptr, b = nullptr;
-        PMF_HIP_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        hipError_t e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            (void)hipEventDestroy(a);
-            pmf_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
-            return PMF_EHIP;
+    while (cm->ev_fin.size() < n) {
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < 3; ++k) {
+            hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+            if (e != hipSuccess) {
+                for (int q = 0; q < k; ++q) (void)hipEventDestroy(ev[q]);
+                pmf_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+                return PMF_EHIP;
+            }
         }
-        cm->ev_ready.push_back(a);
-        cm->ev_done.push_back(b);
+        cm->ev_ready.push_back(ev[0]);
+        cm->ev_done.push_back(ev[1]);
+        cm->ev_fin.push_back(ev[2]);
     }
     return PMF_OK;
 }
@@ -350,6 +364,7 @@ int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out) {
         if (ctx->d_stats[which]) {
             PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
             PMF_HIP_CHECK(hipStreamSynchronize(ctx->comm->stream));
+            PMF_HIP_CHECK(hipStreamSynchronize(ctx->comm->fin_stream));
             pmf_dev_free(ctx, ctx->d_stats[which], ctx->stats_bytes[which]);
             ctx->d_stats[which] = nullptr;
             ctx->stats_bytes[which] = 0;
@@ -362,8 +377,15 @@ int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out) {
     return PMF_OK;
 }
 
-// accumulate(c) -> all-reduce(c) on the collective stream -> finalize(c), pipelined over the row chunks
-// of `side` (`chunked` = false: one message for all rows).  `width` = statistics elements per row.
+// accumulate(c) -> all-reduce(c) -> finalize(c), pipelined over the row chunks of `side` (`chunked` = false: one
+// message for all rows).  `width` = statistics elements per row.  Three streams, ordered by events only:
+//   compute stream      accumulate(0), accumulate(1), ...                       (HBM-bound gathers)
+//   collective stream   all-reduce(c) as soon as accumulate(c) has finished      (xGMI)
+//   finalize stream     finalize(c) as soon as all-reduce(c) has landed          (row solves: VALU / LDS-bound)
+// so the collective of chunk c AND its finalisation run beside the accumulation of the later chunks; the compute
+// stream only waits at the end, for the finalisations it has not already been overtaken by.  (Every rank
+// finalises every item: at BASELINE config C4 that is 1M 128 x 128 row solves per rank and iteration, about
+// 0.1 s -- hidden here instead of queued behind the last accumulate.)
 int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool chunked,
                         const std::function<int()> &accumulate, const std::function<int()> &finalize) {
     PmfComm *cm = ctx->comm;
@@ -372,16 +394,21 @@ int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool 
     int rc = ensure_events(cm, (size_t)n);
     if (rc) return rc;
     const int saved = ctx->cur_chunk[side];
+    hipStream_t const compute = ctx->stream;
+    auto fail = [&](const char *what, hipError_t e) {
+        pmf_set_error("%s failed: %s", what, hipGetErrorString(e));
+        return PMF_EHIP;
+    };
+    int issued = 0;   // chunks whose finalize has been queued
     for (int c = 0; c < n && !rc; ++c) {
         ctx->cur_chunk[side] = chunked ? c : -1;
         if ((rc = accumulate())) break;
         const int64_t r0 = chunked ? pmf_chunk_row0(ctx, side, c) : 0;
         const int64_t r1 = chunked ? pmf_chunk_row0(ctx, side, c + 1) : ctx->rows[side];
-        hipError_t e = hipEventRecord(cm->ev_ready[(size_t)c], ctx->stream);
+        hipError_t e = hipEventRecord(cm->ev_ready[(size_t)c], compute);
         if (e == hipSuccess) e = hipStreamWaitEvent(cm->stream, cm->ev_ready[(size_t)c], 0);
         if (e != hipSuccess) {
-            pmf_set_error("event ordering of the item all-reduce failed: %s", hipGetErrorString(e));
-            rc = PMF_EHIP;
+            rc = fail("event ordering of the item all-reduce", e);
             break;
         }
         pmf_prof_begin_on(ctx, PMF_KERNEL_COMM_ALLREDUCE, cm->stream);
@@ -390,27 +417,36 @@ int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool 
         pmf_prof_end_on(ctx, cm->stream);
         if (rc) break;
         e = hipEventRecord(cm->ev_done[(size_t)c], cm->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cm->fin_stream, cm->ev_done[(size_t)c], 0);
         if (e != hipSuccess) {
-            pmf_set_error("hipEventRecord failed: %s", hipGetErrorString(e));
-            rc = PMF_EHIP;
-        }
-    }
-    for (int c = 0; c < n && !rc; ++c) {
-        ctx->cur_chunk[side] = chunked ? c : -1;
-        pmf_prof_begin_on(ctx, PMF_KERNEL_COMM_WAIT, ctx->stream);   // compute stream idle = exposed communication
-        hipError_t e = hipStreamWaitEvent(ctx->stream, cm->ev_done[(size_t)c], 0);
-        pmf_prof_end_on(ctx, ctx->stream);
-        if (e != hipSuccess) {
-            pmf_set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
-            rc = PMF_EHIP;
+            rc = fail("event ordering of the finalize", e);
             break;
         }
+        ctx->stream = cm->fin_stream;     // the finalize kernels of this chunk go to the finalize stream
         rc = finalize();
+        ctx->stream = compute;
+        if (rc) break;
+        e = hipEventRecord(cm->ev_fin[(size_t)c], cm->fin_stream);
+        if (e != hipSuccess) {
+            rc = fail("hipEventRecord", e);
+            break;
+        }
+        issued = c + 1;
     }
+    // the next half-sweep reads the finalised rows: the compute stream joins the finalize stream here.  Its idle
+    // time in these waits is the communication + finalisation that accumulation did not hide.
+    for (int c = 0; c < issued; ++c) {
+        pmf_prof_begin_on(ctx, PMF_KERNEL_COMM_WAIT, compute);
+        hipError_t e = hipStreamWaitEvent(compute, cm->ev_fin[(size_t)c], 0);
+        pmf_prof_end_on(ctx, compute);
+        if (e != hipSuccess && !rc) rc = fail("hipStreamWaitEvent", e);
+    }
+    ctx->stream = compute;
     ctx->cur_chunk[side] = saved;
-    if (rc) {   // leave no collective half-ordered behind an error
+    if (rc) {   // leave nothing half-ordered behind an error
         (void)hipStreamSynchronize(cm->stream);
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(cm->fin_stream);
+        (void)hipStreamSynchronize(compute);
     }
     return rc;
 }

@@ -155,6 +155,24 @@ def test_two_rank_fit_matches_single_process(kind, tmp_path):
                                        rtol=1e-8, atol=1e-11)
 
 
+@pytest.mark.parametrize("kind,world", [("hpf", 3), ("gauss_pre", 4)])
+def test_more_ranks_than_two_match_single_process(kind, world, tmp_path):
+    """Nothing in the path is specific to two ranks: 3 and 4 ranks on the one GPU (hostshm), full-frame and
+    presharded, against the single-process fit."""
+    base = kind[:-4] if kind.endswith("_pre") else kind
+    train, val = _data()
+    model, keys = _build(base)
+    pred = _fit(base, model, train, val)
+    _spawn(kind, str(tmp_path), world=world)
+    for rank in range(world):
+        d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert int(d["iters"]) == model.history_["iterations"]
+        np.testing.assert_allclose(d["val_rmse"], model.history_["val_rmse"], rtol=1e-10)
+        for k in keys:
+            np.testing.assert_allclose(d[k], getattr(model, k), rtol=1e-9, atol=1e-11, err_msg=k)
+        np.testing.assert_allclose(d["pred"], pred, rtol=1e-9, atol=1e-11)
+
+
 def test_two_rank_gradient_mode_fit_is_consistent(tmp_path):
     """The gradient mode averages the displacements of an item's pieces, so a sharded fit is a
     different (equally valid) trajectory than the single-process one: the ranks must agree with

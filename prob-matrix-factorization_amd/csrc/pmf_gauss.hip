@@ -261,7 +261,7 @@ __device__ __forceinline__ void solve_from_image(const T *img, T wj, int K, int 
         const T uc = (j == k) ? ((T)1 - pinv) : u;
         // column k as scalars first (one batch of v_readlane into SGPRs), then the
         // rank-1 update: back-to-back readlane -> use pairs cost a wait state each
-        constexpr int SB = KR < 32 ? KR : 32;
+        constexpr int SB = sizeof(T) == 8 ? (KR < 16 ? KR : 16) : (KR < 32 ? KR : 32);   // fp64: 16 scalars = 32 SGPRs per batch (32 would spill)
 #pragma unroll
         for (int i0 = 1; i0 < KR; i0 += SB) {
             T sc[SB];

@@ -92,7 +92,7 @@ __device__ __forceinline__ void solve_from_image(const T *img, T wj, int K, int 
 template <typename T, int KS = 0>
 __global__ __launch_bounds__(256) void gauss_accum_generic_kernel(GaussParams<T> p, T inv_sigma2 = (T)0, T inv_eta2 = (T)0,
                                                                   T *cov_self = nullptr, T *factor_self = nullptr) {
-    constexpr int CH = 4;  // chunks per lane per pass -> 64 * CH * 4 = 1024 packed entries per pass
+    constexpr int CH = sizeof(T) == 8 ? 5 : 4;  // chunks per lane per pass -> 64 * CH * 4 packed entries per pass (fp64, K = 64: 2 passes instead of 3)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t task_id = (int64_t)blockIdx.x * 4 + wave;

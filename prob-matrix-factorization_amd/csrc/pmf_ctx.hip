@@ -525,7 +525,7 @@ static int build_work_lists(pmf_ctx *ctx, int side) {
     if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, task_chunk(PMF_GAMMA_CHUNK), true, ix.gamma_tasks))) return rc;
     if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, task_chunk(PMF_GAUSS_CHUNK), false, ix.gauss_tasks))) return rc;
     if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, task_chunk(PMF_GAMMA_CHUNK), false, ix.bias_tasks))) return rc;
-    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_GAMMA_CHUNK, false, ix.sgd_tasks))) return rc;
+    if ((rc = upload_tasks(ctx, side, ix.h_ptr, rows, PMF_SGD_CHUNK, false, ix.sgd_tasks))) return rc;
     return PMF_OK;
 }
 

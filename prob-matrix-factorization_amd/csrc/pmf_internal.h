@@ -92,7 +92,7 @@ struct PmfSideIndex {
     PmfTaskList gamma_tasks;     // chunk = PMF_GAMMA_CHUNK, empty rows included
     PmfTaskList gauss_tasks;     // chunk = PMF_GAUSS_CHUNK, empty rows excluded
     PmfTaskList bias_tasks;      // chunk <= PMF_GAMMA_CHUNK, empty rows excluded
-    PmfTaskList sgd_tasks;       // chunk = PMF_GAMMA_CHUNK exactly (the gradient mode is defined by it), empty rows excluded
+    PmfTaskList sgd_tasks;       // chunk = PMF_SGD_CHUNK exactly (the gradient mode is defined by it), empty rows excluded
 };
 
 struct PmfEvalSet {
@@ -162,7 +162,8 @@ struct pmf_ctx {
     int64_t prof_n[PMF_KERNEL_COUNT] = {};
 };
 
-#define PMF_GAMMA_CHUNK 256
+#define PMF_GAMMA_CHUNK 512   // (256 until round 2: 512 halves the split-row slots; HPF K=64 at C3: gamma_final 0.16 -> 0.08 ms)
+#define PMF_SGD_CHUNK 256     // the gradient mode's piece length is part of its definition (include/pmf_hip.h)
 #define PMF_GAUSS_CHUNK 512
 
 // first row of chunk c of a side (c = n_chunks gives the row count)

@@ -13,6 +13,7 @@
 #include "pmf_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TopkParams {
     const int32_t *users;  // [nq] query user ids (device)
@@ -234,42 +235,59 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int n
 // ---------------------------------------------------------------------------
 // fused score + select, fp32, Kpad <= 128, k <= 64: scores never touch HBM
 // ---------------------------------------------------------------------------
-// One wavefront owns 32 query users for a whole segment of the item range.  Its A operand -- the 32
-// users' factor rows -- is loaded ONCE into KH registers per lane (lane (i = l & 31, h = l >> 5) holds
-// elements [h KH, (h + 1) KH) of user i: the k order of the MFMA steps is a permutation, the same one for
-// both operands) and stays there; per 32-item tile the lane loads the matching half of item (l & 31)'s row
-// (KH / 4 16-byte loads, double-buffered; the 25.6 MB item table is L2 / Infinity-Cache resident and the
-// four waves of a block walk it together), runs KH v_mfma_f32_32x32x2_f32 and compares its 16 scores with
-// the users' current k-th best.  Almost every tile ends there (a user's list changes about k ln(N / k)
-// times over N items); a score that does qualify is inserted into that user's sorted list in LDS by the
-// lanes of the wave in parallel (lane e holds entry e: one compare, one ballot, one shift), in ascending
-// item order, so ties keep the lower item id.  With few query users the item range is cut into segments
-// (gridDim.y) so that the chip is filled; a merge kernel then picks the k best of the segments' lists.
+// One wavefront owns 32 query users for a whole segment of the item range; the four wavefronts of a block
+// walk that range together.  A wave's A operand -- its 32 users' factor rows -- is loaded ONCE into KH
+// registers per lane (lane (i = l & 31, h = l >> 5) holds the 16-byte pieces 2 q + h, q = 0 .. KH / 4 - 1, of
+// user i: the k order of the MFMA steps is a permutation, the same one for both operands) and stays there.
+// The B operand is staged by the block: ST item rows per stage are fetched with fully coalesced 16-byte
+// loads (a thread's piece is contiguous with its neighbours': 2 lines per 256-byte row, where a lane-per-row
+// load touches 64 lines per instruction and left the kernel bound by the texture addresser, 0.58 of the MFMA
+// peak), parked in registers while the previous stage is multiplied, and written to one of two LDS buffers
+// with an odd row pitch (KH / 2 + 1 pieces), from which every wave reads its MFMA layout with conflict-free
+// ds_read_b128 -- each item row leaves the L2 once per 128 users instead of once per 32.  One barrier per
+// stage.  Per 32-item tile a wave runs KH v_mfma_f32_32x32x2_f32 and compares its 16 scores with the users'
+// current k-th best.  Almost every tile ends there (a user's list changes about k ln(N / k) times over N
+// items); a score that does qualify is inserted into that user's sorted list in LDS by the lanes of the
+// wave in parallel (lane e holds entry e: one compare, one ballot, one shift), in ascending item order, so
+// ties keep the lower item id.  With few query users the item range is cut into segments (gridDim.y) so
+// that the chip is filled; a merge kernel then picks the k best of the segments' lists.
 #define TOPK_NEG_INF (-__builtin_inff())
+
+template <int KH>
+struct TopkStage {
+    static constexpr int ST = KH == 64 ? 32 : 64;     // item rows per stage
+    static constexpr int PR = KH / 2;                 // 16-byte pieces per (padded) factor row
+    static constexpr int PQ = PR + 1;                 // LDS row pitch in pieces; odd -> the 16 lanes of a b128 group hit 16 bank quads
+    static constexpr int LPT = ST * PR / 256;         // pieces fetched per thread per stage
+    static constexpr size_t bytes = (size_t)2 * ST * PQ * 16;
+};
 
 template <int KH, int MODE>
 __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const float *fu, const float *fi, const float *cu,
                                                          const float *ci, int k, int64_t seg_items, int nseg,
                                                          float *cand_val, int32_t *cand_idx, int32_t *out_items,
                                                          double *out_scores) {
+    using S = TopkStage<KH>;
+    constexpr int ST = S::ST, PR = S::PR, PQ = S::PQ, LPT = S::LPT;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, c = lane & 31;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
-    if (q0 >= p.nq) return;
-    float *lv = reinterpret_cast<float *>(smem_raw) + (size_t)wave * 32 * k;           // [32][k] values, best first
-    int32_t *li = reinterpret_cast<int32_t *>(smem_raw) + (size_t)(4 + wave) * 32 * k;  // [32][k] item ids
+    const bool active = q0 < p.nq;                     // a wave without users still stages item rows
+    f32x4 *stage = reinterpret_cast<f32x4 *>(smem_raw);                                          // [2][ST][PQ]
+    float *lv = reinterpret_cast<float *>(smem_raw + S::bytes) + (size_t)wave * 32 * k;           // [32][k] values, best first
+    int32_t *li = reinterpret_cast<int32_t *>(smem_raw + S::bytes) + (size_t)(4 + wave) * 32 * k;  // [32][k] item ids
     const int seg = blockIdx.y;
     const int64_t i_begin = (int64_t)seg * seg_items;
     const int64_t i_end = i_begin + seg_items < p.n_items ? i_begin + seg_items : p.n_items;
     const int kpad = p.kpad;
 
-    // A operand: this lane's half of user (q0 + c)'s row, resident for the whole scan
+    // A operand: this lane's pieces of user (q0 + c)'s row, resident for the whole scan
     const int user = (q0 + c < p.nq) ? p.users[q0 + c] : -1;
     float a[KH];
 #pragma unroll
     for (int t = 0; t < KH; t += 4) {
-        const int kk = h * KH + t;
+        const int kk = 2 * t + 4 * h;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (user >= 0 && kk < kpad) v = *reinterpret_cast<const float4 *>(fu + (int64_t)user * kpad + kk);
         a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
@@ -287,19 +305,27 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         lv[e] = TOPK_NEG_INF;
         li[e] = 0x7fffffff;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 
-    auto load_tile = [&](int64_t i0, float (&b)[KH]) {
-        const int64_t it = i0 + c;
-        const bool ok = it < i_end;
-        const float *row = fi + (ok ? it : i_begin) * kpad;
+    // stage: global -> registers (coalesced), registers -> LDS (padded rows)
+    // Loads are unconditional (no branch, nothing for the loop's wait counters to merge): a row past the
+    // segment's end re-reads the last row (its scores are never ranked), a piece past Kpad re-reads the
+    // last piece (the A operand is zero there).
+    f32x4 g[LPT];
+    const int last_piece = kpad / 4 - 1;
+    auto fetch = [&](int64_t i0) __attribute__((always_inline)) {   // (out of line, g[] would live in scratch)
 #pragma unroll
-        for (int t = 0; t < KH; t += 4) {
-            const int kk = h * KH + t;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < kpad) v = *reinterpret_cast<const float4 *>(row + kk);   // (rows of invalid items are never ranked)
-            b[t] = v.x; b[t + 1] = v.y; b[t + 2] = v.z; b[t + 3] = v.w;
+        for (int j = 0; j < LPT; ++j) {
+            const int idx = j * 256 + (int)threadIdx.x;
+            const int r = idx / PR, pc = idx % PR;
+            const int64_t it = i0 + r < i_end ? i0 + r : i_end - 1;
+            g[j] = *reinterpret_cast<const f32x4 *>(fi + it * kpad + 4 * (pc < last_piece ? pc : last_piece));
+        }
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int idx = j * 256 + (int)threadIdx.x;
+            stage[(size_t)buf * ST * PQ + (idx / PR) * PQ + idx % PR] = g[j];
         }
     };
     // insert (v, item) into the list of local user `ul`; returns that list's new k-th best value
@@ -323,13 +349,19 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         return __shfl(pos < k ? nv : ev, k - 1, 64);
     };
 
-    float b0[KH], b1[KH];
-    auto tile = [&](int64_t i0, const float (&b)[KH]) {
+    auto tile = [&](int64_t i0, const f32x4 *rows) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const f32x4 *mine = rows + c * PQ + h;
 #pragma unroll
-        for (int t = 0; t < KH; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+        for (int t = 0; t < KH; t += 4) {
+            const f32x4 b = mine[t / 2];             // piece 2 (t / 4) + h of item (i0 + c)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b.w, acc, 0, 0, 0);
+        }
         const int64_t it = i0 + c;
         const bool ok = it < i_end;
         float ccst = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
@@ -361,14 +393,22 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             }
         }
     };
-    int64_t i0 = i_begin;
-    if (i0 < i_end) load_tile(i0, b0);
-    for (; i0 < i_end; i0 += 64) {
-        if (i0 + 32 < i_end) load_tile(i0 + 32, b1);
-        tile(i0, b0);
-        if (i0 + 32 >= i_end) break;
-        if (i0 + 64 < i_end) load_tile(i0 + 64, b0);
-        tile(i0 + 32, b1);
+    // every wave of the block runs the same number of stages (the barriers below)
+    int buf = 0;
+    fetch(i_begin);                                   // (segments are never empty)
+    stash(0);
+    __syncthreads();
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += ST) {
+        const bool more = i0 + ST < i_end;
+        if (more) fetch(i0 + ST);
+        const f32x4 *rows = stage + (size_t)buf * ST * PQ;
+        if (active) {
+            tile(i0, rows);
+            if (ST == 64 && i0 + 32 < i_end) tile(i0 + 32, rows + 32 * PQ);
+        }
+        if (more) stash(buf ^ 1);                     // last read there: the stage before this one, behind the barrier
+        __syncthreads();
+        buf ^= 1;
     }
     // hand the lists over: final result when the item range was not segmented, else this segment's candidates
     for (int e = lane; e < 32 * k; e += 64) {
@@ -431,19 +471,35 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *cand_val, 
     }
 }
 
+template <int KH, int MODE>
+static hipError_t launch_topk_fused_mode(pmf_ctx *ctx, const TopkParams &p, dim3 grid, size_t list_bytes, const float *fu,
+                                         const float *fi, const float *cu, const float *ci, int k, int64_t seg_items,
+                                         int nseg, float *cand_val, int32_t *cand_idx, int32_t *out_items,
+                                         double *out_scores) {
+    const size_t smem = TopkStage<KH>::bytes + list_bytes;
+    if (smem > (64u << 10)) {   // two stage buffers + long lists (k > ~30 at K > 64): past the default dynamic-LDS limit
+        hipError_t e = hipFuncSetAttribute((const void *)topk_fused_kernel<KH, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((topk_fused_kernel<KH, MODE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
+                       nseg, cand_val, cand_idx, out_items, out_scores);
+    return hipSuccess;
+}
+
 template <int KH>
-static void launch_topk_fused(pmf_ctx *ctx, const TopkParams &p, dim3 grid, size_t smem, int mode, const float *fu,
-                              const float *fi, const float *cu, const float *ci, int k, int64_t seg_items, int nseg,
-                              float *cand_val, int32_t *cand_idx, int32_t *out_items, double *out_scores) {
+static hipError_t launch_topk_fused(pmf_ctx *ctx, const TopkParams &p, dim3 grid, size_t list_bytes, int mode,
+                                    const float *fu, const float *fi, const float *cu, const float *ci, int k,
+                                    int64_t seg_items, int nseg, float *cand_val, int32_t *cand_idx, int32_t *out_items,
+                                    double *out_scores) {
     if (mode == PMF_PREDICT_BIAS)
-        hipLaunchKernelGGL((topk_fused_kernel<KH, PMF_PREDICT_BIAS>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k,
-                           seg_items, nseg, cand_val, cand_idx, out_items, out_scores);
-    else if (mode == PMF_PREDICT_SCALE)
-        hipLaunchKernelGGL((topk_fused_kernel<KH, PMF_PREDICT_SCALE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k,
-                           seg_items, nseg, cand_val, cand_idx, out_items, out_scores);
-    else
-        hipLaunchKernelGGL((topk_fused_kernel<KH, 0>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
-                           nseg, cand_val, cand_idx, out_items, out_scores);
+        return launch_topk_fused_mode<KH, PMF_PREDICT_BIAS>(ctx, p, grid, list_bytes, fu, fi, cu, ci, k, seg_items, nseg,
+                                                            cand_val, cand_idx, out_items, out_scores);
+    if (mode == PMF_PREDICT_SCALE)
+        return launch_topk_fused_mode<KH, PMF_PREDICT_SCALE>(ctx, p, grid, list_bytes, fu, fi, cu, ci, k, seg_items, nseg,
+                                                             cand_val, cand_idx, out_items, out_scores);
+    return launch_topk_fused_mode<KH, 0>(ctx, p, grid, list_bytes, fu, fi, cu, ci, k, seg_items, nseg, cand_val, cand_idx,
+                                         out_items, out_scores);
 }
 
 // fp32, Kpad <= 128, k <= 64
@@ -471,7 +527,7 @@ static int run_topk_fused(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids
     int32_t *d_users = (int32_t *)(base + out_s + out_i);
     float *d_cv = (float *)(base + out_s + out_i + id_bytes);
     int32_t *d_ci = (int32_t *)(base + out_s + out_i + id_bytes + cv_bytes);
-    const size_t smem = (size_t)8 * 32 * k * sizeof(float);
+    const size_t list_bytes = (size_t)8 * 32 * k * sizeof(float);
     for (int64_t at = 0; at < n_query; at += Q) {
         const int nq = (int)std::min<int64_t>(Q, n_query - at);
         PMF_HIP_CHECK(hipMemcpyAsync(d_users, user_ids + at, (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -485,12 +541,14 @@ static int run_topk_fused(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids
             PmfProfScope prof(ctx, PMF_KERNEL_TOPK);
             dim3 grid((unsigned)((nq + 127) / 128), (unsigned)nseg);
             const int kh = ctx->kpad <= 16 ? 8 : ctx->kpad <= 32 ? 16 : ctx->kpad <= 64 ? 32 : 64;
+            hipError_t le;
             switch (kh) {
-                case 8: launch_topk_fused<8>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
-                case 16: launch_topk_fused<16>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
-                case 32: launch_topk_fused<32>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
-                default: launch_topk_fused<64>(ctx, p, grid, smem, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                case 8: le = launch_topk_fused<8>(ctx, p, grid, list_bytes, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                case 16: le = launch_topk_fused<16>(ctx, p, grid, list_bytes, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                case 32: le = launch_topk_fused<32>(ctx, p, grid, list_bytes, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
+                default: le = launch_topk_fused<64>(ctx, p, grid, list_bytes, mode, fu, fi, cu, ci, k, seg_items, nseg, d_cv, d_ci, d_out_items, d_out_scores); break;
             }
+            PMF_HIP_CHECK(le);
             if (nseg > 1)
                 hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, d_cv, d_ci, nq,
                                    (int)n_cand, k, d_out_items, d_out_scores);

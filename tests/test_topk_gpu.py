@@ -106,7 +106,8 @@ def test_fp32_engine_gives_the_reference_top10(case):
     assert exact.mean() > 0.97
 
 
-@pytest.mark.parametrize("K,k,mode", [(64, 10, 0), (64, 64, 1), (128, 10, 2), (20, 7, 1), (12, 33, 0)])
+@pytest.mark.parametrize("K,k,mode", [(64, 10, 0), (64, 64, 1), (128, 10, 2), (20, 7, 1), (12, 33, 0),
+                                       (100, 64, 1)])   # last: stage buffers + 64-entry lists > 64 KB of LDS
 def test_fused_topk_equals_the_two_phase_path(K, k, mode, monkeypatch):
     """The fused kernel (MFMA score tiles + running k best in LDS, item range cut into segments and merged) against
     the two-phase path (score matrix in HBM, then select): same items, scores equal up to the summation order

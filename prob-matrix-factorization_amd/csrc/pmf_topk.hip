@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int n
 
 template <int KH>
 struct TopkStage {
-    static constexpr int ST = KH == 64 ? 32 : 64;     // item rows per stage
+    static constexpr int ST = KH == 8 ? 64 : 32;      // item rows per stage (one MFMA tile; two where a tile is too short a load)
     static constexpr int PR = KH / 2;                 // 16-byte pieces per (padded) factor row
     static constexpr int PQ = PR + 1;                 // LDS row pitch in pieces; odd -> the 16 lanes of a b128 group hit 16 bank quads
     static constexpr int LPT = ST * PR / 256;         // pieces fetched per thread per stage
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     const int q0 = (blockIdx.x * 4 + wave) * 32;
     const bool active = q0 < p.nq;                     // a wave without users still stages item rows
     f32x4 *stage = reinterpret_cast<f32x4 *>(smem_raw);                                          // [2][ST][PQ]
-    float *lv = reinterpret_cast<float *>(smem_raw + S::bytes) + (size_t)wave * 32 * k;           // [32][k] values, best first
-    int32_t *li = reinterpret_cast<int32_t *>(smem_raw + S::bytes) + (size_t)(4 + wave) * 32 * k;  // [32][k] item ids
+    // [32][k] list entries of this wave's users, best first: (item id << 32) | score bits
+    unsigned long long *le = reinterpret_cast<unsigned long long *>(smem_raw + S::bytes) + (size_t)wave * 32 * k;
     const int seg = blockIdx.y;
     const int64_t i_begin = (int64_t)seg * seg_items;
     const int64_t i_end = i_begin + seg_items < p.n_items ? i_begin + seg_items : p.n_items;
@@ -301,12 +301,9 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         ucst[r] = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
         if (MODE != 0 && qq < p.nq) ucst[r] = cu[p.users[qq]];
     }
-    for (int e = lane; e < 32 * k; e += 64) {
-        lv[e] = TOPK_NEG_INF;
-        li[e] = 0x7fffffff;
-    }
+    const unsigned long long empty = ((unsigned long long)0x7fffffffu << 32) | __float_as_uint(TOPK_NEG_INF);
+    for (int e = lane; e < 32 * k; e += 64) le[e] = empty;
 
-    // stage: global -> registers (coalesced), registers -> LDS (padded rows)
     // Loads are unconditional (no branch, nothing for the loop's wait counters to merge): a row past the
     // segment's end re-reads the last row (its scores are never ranked), a piece past Kpad re-reads the
     // last piece (the A operand is zero there).
@@ -330,23 +327,24 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     };
     // insert (v, item) into the list of local user `ul`; returns that list's new k-th best value
     auto insert = [&](int ul, float v, int item) -> float {
-        float *uv = lv + ul * k;
-        int32_t *ui = li + ul * k;
+        unsigned long long *ue = le + ul * k;
         const bool mine = lane < k;
-        const float ev = mine ? uv[lane] : 0.f;
-        const int ei = mine ? ui[lane] : 0;
+        const unsigned long long e = mine ? ue[lane] : 0ull;
+        const float ev = __uint_as_float((unsigned)e);
+        const int ei = (int)(e >> 32);
         const bool before = mine && (ev > v || (ev == v && ei < item));
         const int pos = __popcll(__ballot(before));          // entries that rank before the candidate
-        const float pv = __shfl_up(ev, 1, 64);
-        const int pi = __shfl_up(ei, 1, 64);
+        // entry of the lane below (wave_shr:1; lane 0 is never shifted into: it is either before or at pos)
+        const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)(unsigned)e, 0x138, 0xf, 0xf, false));
+        const int pi = __builtin_amdgcn_update_dpp(0, ei, 0x138, 0xf, 0xf, false);
         float nv = ev;
         int ni = ei;
         if (lane == pos) { nv = v; ni = item; }
         else if (lane > pos) { nv = pv; ni = pi; }
-        if (mine && pos < k) { uv[lane] = nv; ui[lane] = ni; }
+        if (mine && pos < k) ue[lane] = ((unsigned long long)(unsigned)ni << 32) | __float_as_uint(nv);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        return __shfl(pos < k ? nv : ev, k - 1, 64);
+        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pos < k ? nv : ev), k - 1));
     };
 
     auto tile = [&](int64_t i0, const f32x4 *rows) {
@@ -415,8 +413,9 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         const int ul = e / k, t = e % k;
         const int qq = q0 + ul;
         if (qq >= p.nq) continue;
-        const float v = lv[e];
-        const int idx = li[e];
+        const unsigned long long ent = le[e];
+        const float v = __uint_as_float((unsigned)ent);
+        const int idx = (int)(ent >> 32);
         if (nseg == 1) {
             out_items[(int64_t)qq * k + t] = idx == 0x7fffffff ? -1 : idx;
             out_scores[(int64_t)qq * k + t] = idx == 0x7fffffff ? 0.0 : (double)v;

@@ -7,7 +7,8 @@ import collections, csv, glob, json, os, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dominant = {"gaussian_mf": ("gauss_accum", "gauss_accum_mfma_kernel"), "hpf_cavi": ("gamma_sweep", "gamma_sweep_kernel")}
+dominant = {"gaussian_mf": ("gauss_accum", "gauss_accum_mfma_kernel"), "hpf_cavi": ("gamma_sweep", "gamma_sweep_kernel"),
+            "gaussian_mf_k128": ("gauss_accum", "gauss_accum_mfma128_kernel")}
 rows, traffic = [], {}
 for w, (cls, kname) in dominant.items():
     per = collections.defaultdict(dict)

@@ -24,6 +24,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c"
   rocprofv3 --pmc $c --output-format csv -d "$R/gpurun_out/pmc_gaussian_mf_$c" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --only > "$O/pmc_gauss_$c.out" 2> "$O/pmc_gauss_$c.err" || { echo FAILED; tail -5 "$O/pmc_gauss_$c.err"; }
   rocprofv3 --pmc $c --output-format csv -d "$R/gpurun_out/pmc_hpf_cavi_$c" -- python3 "$R/bench.py" --workload hpf_cavi --steps 4 --warmup 1 --no-cpu-baseline > "$O/pmc_hpf_$c.out" 2> "$O/pmc_hpf_$c.err" || { echo FAILED; tail -5 "$O/pmc_hpf_$c.err"; }
+  rocprofv3 --pmc $c --output-format csv -d "$R/gpurun_out/pmc_gaussian_mf_k128_$c" -- python3 "$R/bench.py" --workload gaussian_mf_k128 --steps 1 --warmup 1 --no-cpu-baseline > "$O/pmc_k128_$c.out" 2> "$O/pmc_k128_$c.err" || { echo FAILED; tail -5 "$O/pmc_k128_$c.err"; }
 done
 # keep the merge small: only the stats / counter summaries travel back
 find "$R/gpurun_out" -name "*kernel_trace.csv" -delete

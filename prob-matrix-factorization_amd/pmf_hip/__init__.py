@@ -126,6 +126,9 @@ def load():
     # drivers do so at import time; PMF_HIP_TORCH_PRELOAD=1 forces it here.
     global _loaded_before_torch
     _loaded_before_torch = "torch" not in sys.modules
+    # RCCL between processes needs dmabuf IPC on hosts whose driver has no legacy IPC (hipIpcGetMemHandle:
+    # invalid argument otherwise); the runtime reads this when it initialises, i.e. after this point.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if _loaded_before_torch and os.environ.get("PMF_HIP_TORCH_PRELOAD") == "1":
         try:
             import torch  # noqa: F401

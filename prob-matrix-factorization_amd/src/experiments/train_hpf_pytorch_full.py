@@ -55,13 +55,14 @@ def _graphed_step(model, optimizer, batch_size, u, i, r):
     return static_idx, static_loss, graph
 
 
-def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=1, graph=None):
+def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=1, graph=None, on_epoch=None):
     """The reference's external training loop (train_hpf_pytorch_full.py:96-108):
     Adam over all parameters, shuffled minibatches, one pass per epoch.
 
     On a GPU the full-size batches replay one captured HIP graph (`graph=False` or
     PMF_TORCH_GRAPH=0 keeps the eager loop) and the epoch loss is accumulated on the device
-    (one read-back per epoch instead of one per step)."""
+    (one read-back per epoch instead of one per step).  `on_epoch(epoch)` runs after every pass (the
+    grid search's per-epoch validation, tune_hpf_pytorch.py:83-95)."""
     import os
     on_gpu = r.device.type == "cuda"
     n = len(r)
@@ -91,6 +92,8 @@ def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=
             total += loss.detach()
         if verbose and (epoch % log_every == 0 or epoch == epochs - 1):
             print(f"Epoch {epoch + 1}/{epochs} Loss: {total.item():.4f}")
+        if on_epoch is not None:
+            on_epoch(epoch)
     model.training_info_ = {"graph_replays": replays, "steps": epochs * ((n + batch_size - 1) // batch_size)}
     return model
 

@@ -87,3 +87,30 @@ def test_hpf_pytorch_matches_reference_loss_and_gradients(golden_dir):
     from helpers import GOLDEN  # noqa: F401
     pu = np.array([0, 1, 2, 299]) % int(d["n_users"]); pi = np.array([0, 79, 80, 3]) % int(d["n_items"])
     np.testing.assert_allclose(m.predict(pu, pi), d["predict"], rtol=1e-6)
+
+
+def test_tune_hpf_pytorch_grid_protocol(capsys):
+    """The grid search of tune_hpf_pytorch.py: every combination of the grid, the combination's score = its
+    best per-epoch validation RMSE on the un-shifted scale, the reference's printed lines, input frames untouched."""
+    import torch
+    from src.experiments import tune_hpf_pytorch as tp
+    assert tp.PARAM_GRID == {"n_factors": [20, 50], "lr": [0.001, 0.005], "a": [0.3, 1.0], "a_prime": [1.0, 3.0]}
+    assert (tp.EPOCHS, tp.BATCH_SIZE) == (10, 4096)
+    rng = np.random.default_rng(3)
+
+    def frame(n):
+        return pd.DataFrame({"u": rng.integers(0, 60, n), "i": rng.integers(0, 40, n),
+                             "rating": rng.integers(0, 6, n).astype(float)})
+    train, val, test = frame(1500), frame(200), frame(100)
+    test.loc[0, "u"] = 77                      # the dimensions come from all three splits
+    before = train["rating"].copy()
+    torch.manual_seed(0)
+    best, best_rmse, results = tp.run_tuning(splits=(train, val, test), epochs=2, batch_size=256,
+                                             param_grid={"n_factors": [4, 6], "lr": [0.01], "a": [0.3], "a_prime": [1.0, 3.0]})
+    assert train["rating"].equals(before)
+    assert len(results) == 4 and all(np.isfinite(s) for _, s in results)
+    assert best_rmse == min(s for _, s in results) and best in [p for p, _ in results]
+    out = capsys.readouterr().out
+    assert "Total combinations to test: 4" in out and "--- Run 4/4: " in out
+    assert out.count("Result RMSE: ") == 4 and f"Best Validation RMSE: {best_rmse:.4f}" in out
+    assert "*** New Best RMSE: " in out and f"Best Configuration: {best}" in out

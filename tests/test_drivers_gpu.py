@@ -239,3 +239,24 @@ def test_hpf_pytorch_on_cuda_matches_the_reference_golden(golden_dir):
         g = d["grad_" + name.split("_")[0]]
         moved = np.abs(g) > 1e-4
         np.testing.assert_allclose((a - d[name])[moved], -1e-2 * np.sign(g[moved]), rtol=1e-3, atol=1e-6, err_msg=name)
+
+
+def test_tune_hpf_pytorch_grid_on_cuda(capsys):
+    """The PyTorch HPF grid search with the module and the ratings on the GPU: the captured Adam step is replayed
+    inside every combination, the per-epoch validation hook sees the updated parameters (the score improves over
+    the epochs on learnable data), and the best combination is the minimum of the per-combination scores."""
+    import torch
+    from pmf_hip.synth import synth_ratings
+    from src.experiments import tune_hpf_pytorch as tp
+    u, i, r = synth_ratings(2000, 500, 60_000, seed=11)
+    frames = []
+    for lo, hi in ((0, 50_000), (50_000, 56_000), (56_000, 60_000)):
+        frames.append(pd.DataFrame({"u": u[lo:hi].astype(np.int64), "i": i[lo:hi].astype(np.int64), "rating": r[lo:hi]}))
+    torch.manual_seed(0)
+    best, best_rmse, results = tp.run_tuning(splits=tuple(frames), epochs=3, batch_size=4096,
+                                             param_grid={"n_factors": [8], "lr": [0.02, 0.0001], "a": [0.3], "a_prime": [1.0]})
+    assert len(results) == 2 and best_rmse == min(s for _, s in results)
+    scores = {p["lr"]: s for p, s in results}
+    assert scores[0.02] < scores[0.0001]          # three epochs at lr 1e-4 barely move the parameters
+    assert best["lr"] == 0.02
+    assert "Total combinations to test: 2" in capsys.readouterr().out

@@ -1,0 +1,141 @@
+"""Randomised parity sweep: the model classes (HIP engine, f64 parity mode and f32) against the CPU oracle on many
+small random problems -- odd shapes (one user, one item, one factor, one rating), duplicates, rows far longer than a
+task, empty rows, validation ids outside the training range.  Prints the worst deviation per model kind and every
+failing case.  Test infrastructure (it drives the oracle): `tests/test_fuzz_gpu.py` runs a short sweep;
+    python tests/fuzz_parity.py [n_trials] [seed]    runs a long one."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "prob-matrix-factorization_amd"), ROOT]
+import numpy as np, pandas as pd
+from oracle import cavi_oracle as orc
+from src.models.hpf_cavi import HPF_CAVI, HPF_CAVI_Config
+from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
+from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVI, PoissonMFExtendedCAVIConfig
+from src.models import gaussian_mf_cavi as gnb, gaussian_mf_cavi_bias as gb
+
+KEYS = {
+    "hpf": ["gamma_a_theta", "gamma_b_theta", "gamma_a_beta", "gamma_b_beta", "E_theta", "E_beta", "E_xi", "E_eta",
+            "gamma_b_xi", "gamma_b_eta"],
+    "poisson": ["a_theta", "b_theta", "a_beta", "b_beta", "E_theta", "E_beta"],
+    "poisson_ext": ["a_theta", "b_theta", "a_beta", "b_beta", "a_phi", "b_phi", "a_psi", "b_psi", "E_theta", "E_beta",
+                    "E_phi", "E_psi"],
+    "gauss_bias": ["m_theta", "m_beta", "V_theta", "V_beta", "m_user_bias", "m_item_bias"],
+    "gauss": ["m_theta", "m_beta", "V_theta", "V_beta"],
+}
+
+
+def problem(rng):
+    shape = rng.choice(["tiny", "one_user", "one_item", "heavy_row", "plain", "sparse"])
+    U, I = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+    N = int(rng.integers(1, 500))
+    if shape == "tiny":
+        U, I, N = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 6))
+    if shape == "one_user":
+        U = 1
+    if shape == "one_item":
+        I = 1
+    u, i = rng.integers(0, U, N), rng.integers(0, I, N)
+    if shape == "heavy_row":                      # one row holds most ratings (several tasks), duplicates included
+        u[: (3 * N) // 4] = int(rng.integers(0, U))
+        i[: N // 2] = int(rng.integers(0, I))
+    if shape == "sparse":                         # ids far apart: most rows are empty
+        U, I = U * 7, I * 5
+        u, i = u * 7, i * 5
+    x = rng.integers(0, 6, N).astype(np.float64)
+    nv = int(rng.integers(1, 40))
+    vu, vi = rng.integers(0, U + 3, nv), rng.integers(0, I + 3, nv)      # some ids outside the training range
+    vx = rng.integers(0, 6, nv).astype(np.float64)
+    return shape, u, i, x, (vu, vi, vx)
+
+
+def run(kind, dtype, u, i, x, val, K, seed, iters):
+    train = pd.DataFrame({"u": u, "i": i, "rating": x})
+    vdf = pd.DataFrame({"u": val[0], "i": val[1], "rating": val[2]})
+    gm = 0.0
+    if kind == "hpf":
+        cfg = dict(n_factors=K, a=0.3, a_prime=2.0, b_prime=1.5, c=0.4, c_prime=3.0, d_prime=0.7, max_iter=iters, tol=None,
+                   random_state=seed)
+        train["rating"] += 1; vdf["rating"] += 1
+        m = HPF_CAVI(HPF_CAVI_Config(verbose=False, **cfg), dtype=dtype)
+    elif kind == "poisson":
+        cfg = dict(n_factors=K, a0=0.2, b0=0.6, max_iter=iters, tol=None, random_state=seed)
+        m = PoissonMFCAVI(PoissonMFCAVIConfig(verbose=False, **cfg), dtype=dtype)
+    elif kind == "poisson_ext":
+        cfg = dict(n_factors=K, a0=0.2, b0=0.6, max_iter=iters, tol=None, random_state=seed)
+        train["rating"] += 1; vdf["rating"] += 1
+        m = PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(verbose=False, **cfg), dtype=dtype)
+    else:
+        cfg = dict(n_factors=K, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, max_iter=iters, tol=-1e9, random_state=seed)
+        gm = float(train["rating"].mean())
+        train["rating"] -= gm; vdf["rating"] -= gm
+        if kind == "gauss_bias":
+            cfg["eta_bias2"] = 1.3
+            m = gb.GaussianMFCAVI(gb.GaussianMFCAVIConfig(verbose=False, **cfg), dtype=dtype)
+        else:
+            m = gnb.GaussianMFCAVI(gnb.GaussianMFCAVIConfig(verbose=False, **cfg), dtype=dtype)
+    tr = (train["u"].to_numpy(), train["i"].to_numpy(), train["rating"].to_numpy())
+    va = (vdf["u"].to_numpy(), vdf["i"].to_numpy(), vdf["rating"].to_numpy())
+    if kind.startswith("gauss"):
+        m.fit(train, vdf, global_mean=gm)
+    else:
+        m.fit(train, vdf)
+    st, hist = orc.fit(kind, *tr, cfg, val=va, global_mean=gm)
+    worst = 0.0
+    for key in KEYS[kind]:
+        got, want = np.asarray(getattr(m, key), dtype=np.float64), np.asarray(st[key], dtype=np.float64)
+        if got.shape != want.shape:
+            return float("inf"), f"{key}: shape {got.shape} != {want.shape}"
+        scale = max(1.0, float(np.max(np.abs(want))) if want.size else 1.0)
+        err = float(np.max(np.abs(got - want))) / scale if want.size else 0.0
+        if not np.isfinite(err):
+            return float("inf"), f"{key}: non-finite"
+        worst = max(worst, err)
+    hv = np.asarray(m.history_["val_rmse"], dtype=np.float64)
+    ov = np.asarray(hist["val_rmse"], dtype=np.float64)
+    if hv.shape != ov.shape:
+        return float("inf"), f"val_rmse trajectory length {hv.shape} != {ov.shape}"
+    both_nan = np.isnan(hv) & np.isnan(ov)
+    if hv.size and not np.all(both_nan | (np.abs(hv - ov) <= 1e-6 * np.maximum(1.0, np.abs(ov)) + (0 if dtype == "f64" else 1e-3))):
+        return float("inf"), f"val_rmse {hv} != {ov}"
+    if hasattr(m, "close"):
+        m.close()
+    return worst, ""
+
+
+def sweep(n_trials, seed, quiet=False):
+    """Returns (failures, {(kind, dtype): worst deviation})."""
+    rng = np.random.default_rng(seed)
+    worst = {}
+    bad = 0
+    for t in range(n_trials):
+        kind = str(rng.choice(list(KEYS)))
+        dtype = str(rng.choice(["f64", "f64", "f32"]))
+        K = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 24, 31, 32, 33, 40, 48, 49, 56, 57, 64, 65, 72, 80, 96, 100, 128, 130]))
+        if kind.startswith("gauss") and K > 64 and rng.random() < 0.5:
+            K = int(rng.integers(1, 64))              # keep most Gaussian cases cheap for the CPU oracle
+        shape, u, i, x, val = problem(rng)
+        seed, iters = int(rng.integers(0, 1000)), int(rng.integers(1, 4))
+        tol = 1e-9 if dtype == "f64" else 5e-3
+        try:
+            err, msg = run(kind, dtype, u, i, x, val, K, seed, iters)
+        except Exception as e:     # noqa: BLE001 -- the sweep reports and goes on
+            err, msg = float("inf"), f"{type(e).__name__}: {e}"
+        key = (kind, dtype)
+        if err <= tol:
+            worst[key] = max(worst.get(key, 0.0), err)
+        else:
+            bad += 1
+            print(f"FAIL trial {t}: {kind} {dtype} K={K} shape={shape} U={u.max() + 1} I={i.max() + 1} N={len(u)} seed={seed} "
+                  f"iters={iters}: err={err:.3e} {msg}", flush=True)
+        if not quiet and t % 500 == 499:
+            print(f"... {t + 1} trials, {bad} failures", flush=True)
+    return bad, worst
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    failures, worst_by_kind = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    for k in sorted(worst_by_kind):
+        print(f"{k[0]:12s} {k[1]}: worst relative deviation {worst_by_kind[k]:.2e}")
+    print(f"{n} trials, {failures} failures")
+    sys.exit(1 if failures else 0)

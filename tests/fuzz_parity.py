@@ -132,10 +132,92 @@ def sweep(n_trials, seed, quiet=False):
     return bad, worst
 
 
+def sweep_three_stage(n_trials, seed, quiet=False):
+    """The multi-GPU code path against the fused one, on random problems: a context with a ONE-rank RCCL
+    communicator runs its ITEM half-sweeps as accumulate -> ncclAllReduce per row chunk -> finalize on three
+    streams, over a random number of item row chunks; a plain context runs the fused sweeps.  Same rows, same
+    arithmetic: the states must agree to rounding (the split-row sums are combined in another kernel).
+    Returns (failures, worst deviation)."""
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ARR_PRIOR_RATE, ARR_RATE, ARR_SHAPE, ITEM, USER, dist as pdist
+    from pmf_hip.engine import Context
+    rng = np.random.default_rng(seed)
+    comm = pdist.Comm(0, 1, 0, Context.comm_unique_id(), "rccl")
+    bad, worst = 0, 0.0
+    try:
+        for t in range(n_trials):
+            kind = str(rng.choice(["poisson", "hpf", "gauss", "sgd"]))
+            dtype = str(rng.choice(["f64", "f32"]))
+            K = int(rng.choice([1, 3, 8, 16, 20, 32, 33, 40, 50, 56, 64, 72, 96, 128, 140]))
+            shape, u, i, x, _ = problem(rng)
+            U, I = int(u.max()) + 1, int(i.max()) + 1
+            n_chunks = int(rng.integers(1, min(I, 6) + 1))
+            a_u, a_i = rng.gamma(1.0, 0.3, (U, K)) + 0.05, rng.gamma(1.0, 0.3, (I, K)) + 0.05
+            m_u, m_i = 0.1 * rng.standard_normal((U, K)), 0.1 * rng.standard_normal((I, K))
+            states = []
+            try:
+                for with_comm in (True, False):
+                    with pmf_hip.Context(U, I, K, dtype=dtype) as ctx:
+                        if with_comm:
+                            comm.attach(ctx)
+                            ctx.set_row_chunks(ITEM, n_chunks)
+                        if kind in ("poisson", "hpf"):
+                            ctx.set_ratings(u, i, x + 1.0)
+                            ctx.set_array(USER, ARR_FACTOR, a_u); ctx.set_array(ITEM, ARR_FACTOR, a_i)
+                            if kind == "hpf":
+                                ctx.set_array(USER, ARR_PRIOR_RATE, np.full(U, 1.3)); ctx.set_array(ITEM, ARR_PRIOR_RATE, np.full(I, 0.8))
+                            for _ in range(2):
+                                for side in (USER, ITEM):
+                                    if kind == "hpf":
+                                        ctx.gamma_sweep(side, 0.3, 0.0, True, 2.0 + K * 0.3, 1.5)
+                                    else:
+                                        ctx.gamma_sweep(side, 0.2, 0.6)
+                            arrays = [(s, a) for s in (USER, ITEM) for a in (ARR_SHAPE, ARR_RATE, ARR_FACTOR)]
+                            if kind == "hpf":
+                                arrays += [(USER, ARR_PRIOR_RATE), (ITEM, ARR_PRIOR_RATE)]
+                        else:
+                            ctx.set_ratings(u, i, x - x.mean())
+                            ctx.set_array(USER, ARR_FACTOR, m_u); ctx.set_array(ITEM, ARR_FACTOR, m_i)
+                            ctx.set_array(USER, ARR_BIAS, np.zeros(U)); ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
+                            if kind == "gauss":
+                                ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
+                            for _ in range(2):
+                                if kind == "gauss":
+                                    ctx.gauss_factor_sweep(USER, 0.4, 0.6); ctx.gauss_factor_sweep(ITEM, 0.4, 0.9)
+                                    ctx.gauss_bias_sweep(USER, 0.4, 1.3); ctx.gauss_bias_sweep(ITEM, 0.4, 1.3)
+                                else:
+                                    ctx.gauss_sgd_sweep(USER, 0.05, 0.4, 0.6, 1.3); ctx.gauss_sgd_sweep(ITEM, 0.05, 0.4, 0.9, 1.3)
+                            arrays = [(s, a) for s in (USER, ITEM) for a in (ARR_FACTOR, ARR_BIAS)]
+                            if kind == "gauss":
+                                arrays += [(USER, ARR_COV), (ITEM, ARR_COV)]
+                        states.append([ctx.get_array(s, a) for s, a in arrays])
+                err = 0.0
+                for got, want in zip(*states):
+                    scale = max(1.0, float(np.max(np.abs(want))) if want.size else 1.0)
+                    e = float(np.max(np.abs(got - want))) / scale if want.size else 0.0
+                    err = max(err, e if np.isfinite(e) else float("inf"))
+                msg = ""
+            except Exception as e:     # noqa: BLE001
+                err, msg = float("inf"), f"{type(e).__name__}: {e}"
+            if err <= (1e-11 if dtype == "f64" else 2e-4):
+                worst = max(worst, err) if dtype == "f32" else worst
+            else:
+                bad += 1
+                print(f"FAIL three-stage trial {t}: {kind} {dtype} K={K} shape={shape} U={U} I={I} N={len(u)} "
+                      f"chunks={n_chunks}: err={err:.3e} {msg}", flush=True)
+            if not quiet and t % 500 == 499:
+                print(f"... three-stage {t + 1} trials, {bad} failures", flush=True)
+    finally:
+        comm.close()
+    return bad, worst
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     failures, worst_by_kind = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     for k in sorted(worst_by_kind):
         print(f"{k[0]:12s} {k[1]}: worst relative deviation {worst_by_kind[k]:.2e}")
     print(f"{n} trials, {failures} failures")
-    sys.exit(1 if failures else 0)
+    f3, w3 = sweep_three_stage(n // 2, 7)
+    print(f"three-stage path vs fused sweeps: {n // 2} trials, {f3} failures, worst f32 deviation {w3:.2e}")
+    sys.exit(1 if failures or f3 else 0)

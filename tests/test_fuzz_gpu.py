@@ -13,3 +13,11 @@ def test_random_small_problems_match_the_oracle(capsys):
     assert len(worst) == 10                      # five kinds x two dtypes were all drawn
     for (kind, dtype), err in worst.items():
         assert err <= (1e-12 if dtype == "f64" else 1e-4), (kind, dtype, err)
+
+
+def test_random_problems_through_the_three_stage_path(capsys):
+    """accumulate -> ncclAllReduce (one-rank RCCL) per item row chunk -> finalize against the fused sweeps."""
+    import fuzz_parity
+    failures, worst = fuzz_parity.sweep_three_stage(80, seed=3, quiet=True)
+    assert failures == 0, capsys.readouterr().out
+    assert worst <= 2e-4

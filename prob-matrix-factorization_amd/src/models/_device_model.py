@@ -50,11 +50,17 @@ class DeviceModel:
         `presharded=True` (with `comm`): `fit` is given only THIS RANK's training rows instead -- global
         user ids, rank r holding a contiguous id range that lies above rank r-1's -- so no rank ever
         holds the full frame (12 GB per rank at BASELINE config C4); dimensions and the ranges are
-        agreed by small all-reduces.  Either way the initial state is drawn with the reference's RNG
-        sequence and a rank keeps only its own users' rows of it."""
+        agreed by small all-reduces.  `presharded=bounds` (world + 1 ascending user ids, bounds[0] = 0) states the
+        ranges instead of having them derived from the rows: rank r owns users [bounds[r], bounds[r + 1]) -- the
+        way to say where users WITHOUT training rows belong, which decides the rank that must be handed their
+        validation rows (derived ranges give such users to the next rank above that has training rows).
+        Rows outside their rank's range are refused on every rank alike.  Either way the initial state is drawn
+        with the reference's RNG sequence and a rank keeps only its own users' rows of it."""
         self.config = config
         self._comm = comm if (comm is not None and comm.world > 1) else None
-        self._presharded = bool(presharded) and self._comm is not None
+        explicit = presharded is not None and not isinstance(presharded, (bool, np.bool_))
+        self._given_bounds = np.asarray(presharded, dtype=np.int64) if explicit else None
+        self._presharded = (explicit or bool(presharded)) and self._comm is not None
         self._bounds = None
         self.n_users = None
         self.n_items = None
@@ -91,6 +97,21 @@ class DeviceModel:
             self._bounds = pdist.shard_bounds(train_df["u"].to_numpy(dtype=int), self.n_users, comm.world)
             return
         u = train_df["u"].to_numpy(dtype=int)
+        if self._given_bounds is not None:
+            b = self._given_bounds
+            if b.shape != (comm.world + 1,) or b[0] != 0 or (np.diff(b) < 0).any():
+                raise ValueError(f"presharded bounds must be {comm.world + 1} ascending user ids starting at 0, got {b}")
+            b = np.minimum(b, self.n_users)        # n_users = highest training id + 1, as in the reference
+            b[-1] = self.n_users
+            lo, hi = int(b[comm.rank]), int(b[comm.rank + 1])
+            stray = comm.all_reduce_host([float(((u < lo) | (u >= hi)).sum())])[0]
+            if stray:
+                raise ValueError(f"presharded fit: {int(stray)} training row(s) lie outside their rank's user range {b}")
+            empty = [r for r in range(comm.world) if b[r + 1] <= b[r]]
+            if empty:
+                raise ValueError(f"presharded fit: rank(s) {empty} hold no user range in {b} (n_users = {self.n_users})")
+            self._bounds = b
+            return
         top = np.zeros(comm.world)
         low = np.full(comm.world, 0.0)
         top[comm.rank] = float(u.max()) + 1 if len(u) else 0.0
@@ -103,6 +124,10 @@ class DeviceModel:
             if low[r] < bounds[r] and top[r] > bounds[r]:
                 raise ValueError(f"presharded fit: rank {r}'s user ids start at {int(low[r])}, inside rank {r - 1}'s range "
                                  f"(< {int(bounds[r])}); every rank must hold a contiguous user-id range above the previous rank's")
+        empty = [r for r in range(comm.world) if bounds[r + 1] <= bounds[r]]
+        if empty:      # the same on every rank (the bounds come from all-reduced values): all ranks raise together
+            raise ValueError(f"presharded fit: rank(s) {empty} hold no user range (no training rows, and no user ids left "
+                             f"above the previous rank's); use fewer ranks or give every rank at least one user")
         self._bounds = bounds
 
     def _user_rows(self, draw):
@@ -214,7 +239,9 @@ class DeviceModel:
         if drop_unseen:  # gaussian_mf_cavi_bias.py:323-331
             keep = (vu < self.n_users) & (vi < self.n_items)
             vu, vi, vy = vu[keep], vi[keep], vy[keep]
-            if len(vy) == 0:
+            if len(vy) == 0 and not (self._comm is not None and self._presharded):
+                # (presharded: this rank's rows are not the whole validation set; an empty share must still take
+                # part in the collectives of _sharded_monitor, which reports the globally empty case itself)
                 def empty():
                     print("Warning: No valid (u,i) pairs.")
                     return float("nan"), float("nan")
@@ -222,7 +249,7 @@ class DeviceModel:
         y = vy + offset if drop_unseen else vy
         ctx = self._ctx
         if self._comm is not None:
-            return self._sharded_monitor(vu, vi, y, offset)
+            return self._sharded_monitor(vu, vi, y, offset, warn_empty=drop_unseen)
         if ctx.eval_set(vu, vi, y):
             return lambda: ctx.eval_run(self._uses_bias, offset)
         # too many distinct labels for the fused reduction: device predict + host metrics
@@ -244,7 +271,7 @@ class DeviceModel:
         self._t_last = now
         self.history_["iterations"] = it
 
-    def _sharded_monitor(self, vu, vi, y, offset):
+    def _sharded_monitor(self, vu, vi, y, offset, warn_empty=False):
         """Every rank scores the validation pairs of its own users (pairs with an unseen
         user go to the last rank, where the id stays out of range and predicts 0); the
         additive sums are all-reduced."""
@@ -266,12 +293,23 @@ class DeviceModel:
         lo, hi = int(self._bounds[comm.rank]), int(self._bounds[comm.rank + 1])
         last = comm.rank == comm.world - 1
         mine = (vu >= lo) & ((vu < hi) | last)
+        if self._presharded:
+            # a row handed to the wrong rank would silently drop out of the metric: refuse it, on every rank alike
+            stray = comm.all_reduce_host([float((~mine).sum())])[0]
+            if stray:
+                raise ValueError(f"presharded fit: {int(stray)} validation row(s) were given to a rank that does not own "
+                                 f"their user (ranges {self._bounds.tolist()}; ids >= n_users go to the last rank); pass "
+                                 f"`presharded=bounds` to state the ranges")
         lu = np.where(vu[mine] < self.n_users, vu[mine] - lo, np.iinfo(np.int32).max)
         have = ctx.eval_set(lu, vi[mine], y[mine], labels=labels) if mine.any() else False
 
         def run():
-            sums = ctx.eval_sums(self._uses_bias, offset) if have else np.zeros(2 + 2 * MAX_LABELS)
-            return ctx.metrics_from_sums(comm.all_reduce_host(sums))
+            sums = comm.all_reduce_host(ctx.eval_sums(self._uses_bias, offset) if have else np.zeros(2 + 2 * MAX_LABELS))
+            if sums[0] == 0:      # no rank holds a scorable pair
+                if warn_empty:    # gaussian_mf_cavi_bias.py:326-328
+                    print("Warning: No valid (u,i) pairs.")
+                return float("nan"), float("nan")
+            return ctx.metrics_from_sums(sums)
         return run
 
     def _record(self, rmse_v, mae_v):

@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pandas as pd
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -270,3 +271,78 @@ def test_sharded_model_fit_host_logic_over_gloo(kind, tmp_path):
                 np.testing.assert_allclose(d[k], one[k], rtol=1e-9, atol=1e-11, err_msg=k)
     if kind == "gauss":
         assert np.load(os.path.join(tmp_path, "w2_rank0.npz"))["V_theta"].shape == (300, 5, 5)
+
+
+def _contract_worker(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as tdist
+    import pmf_hip
+    from oracle_engine import AttachingGlooComm, OracleContext
+    from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
+    pmf_hip.Context = OracleContext
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = AttachingGlooComm()
+    rng = np.random.default_rng(5)
+    # users 0, 1 | 2 (no training rows) | 3, 4, 5; explicit ranges [0, 3) and [3, 6); derived ones [0, 2) and [2, 6)
+    tu = np.array([0, 0, 1, 1, 1, 3, 4, 4, 5, 5, 5, 3]); ti = rng.integers(0, 4, len(tu)); ti[0] = 3
+    train = pd.DataFrame({"u": tu, "i": ti, "rating": rng.integers(0, 6, len(tu)).astype(float)})
+    gm = float(train["rating"].mean())
+    cfg = GaussianMFCAVIConfig(n_factors=3, sigma2=0.3, eta_theta2=0.5, eta_beta2=0.5, eta_bias2=1.0, max_iter=3,
+                               tol=-1.0, verbose=False)
+    mine = train[train["u"] < 3] if rank == 0 else train[train["u"] >= 3]
+    centred = lambda df: df.assign(rating=df["rating"] - gm)      # noqa: E731
+    out = {}
+
+    def sharded(val, presharded, split):
+        lo, hi = split[rank], split[rank + 1]
+        part = val[(val["u"] >= lo) & ((val["u"] < hi) | (rank == world - 1))]
+        m = GaussianMFCAVI(cfg, dtype="f64", comm=comm, presharded=presharded)
+        m.fit(centred(mine), centred(part), global_mean=gm)
+        return np.array(m.history_["val_rmse"]), m.m_theta
+
+    def single(val):
+        m = GaussianMFCAVI(cfg, dtype="f64")
+        m.fit(centred(train), centred(val), global_mean=gm)
+        return np.array(m.history_["val_rmse"]), m.m_theta
+
+    # A: every validation row belongs to rank 0 -- rank 1's share is empty and must still join the collectives
+    val_a = pd.DataFrame({"u": [0, 1, 1, 9], "i": [0, 1, 2, 1], "rating": [4.0, 5.0, 3.0, 2.0]})
+    val_a = val_a[val_a["u"] < 6]                       # (the unseen id would go to the last rank)
+    got, theta = sharded(val_a, True, [0, 2, 6])
+    want, theta1 = single(val_a)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    np.testing.assert_allclose(theta, theta1, rtol=1e-9, atol=1e-12)
+    # B: user 2 has no training rows; explicit ranges put it on rank 0, and so do the validation rows
+    val_b = pd.DataFrame({"u": [2, 0, 4, 5, 7], "i": [0, 1, 2, 1, 0], "rating": [4.0, 5.0, 3.0, 2.0, 1.0]})
+    got, _ = sharded(val_b, np.array([0, 3, 6]), [0, 3, 6])
+    want, _ = single(val_b)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    # C: the same rows under DERIVED ranges ([0, 2) | [2, 6)): user 2's row sits on the wrong rank -> refused everywhere
+    try:
+        sharded(val_b, True, [0, 3, 6])
+        out["stray"] = "accepted"
+    except ValueError as e:
+        out["stray"] = str(e)
+    # D: explicit ranges that do not contain the rows -> refused everywhere
+    try:
+        sharded(val_a, np.array([0, 1, 6]), [0, 2, 6])
+        out["bad_bounds"] = "accepted"
+    except ValueError as e:
+        out["bad_bounds"] = str(e)
+    with open(os.path.join(out_dir, f"contract{rank}.txt"), "w") as fh:
+        fh.write(out["stray"] + "\n" + out["bad_bounds"] + "\n")
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_presharded_contract_over_gloo(tmp_path):
+    """Presharded fits: a rank with no validation rows keeps step with the others (its share of the all-reduced
+    sums is zero); explicit user ranges (`presharded=bounds`) place users without training rows; rows on the
+    wrong rank are refused on every rank instead of dropping out of the metric."""
+    import torch.multiprocessing as mp
+    mp.spawn(_contract_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        stray, bad = open(os.path.join(tmp_path, f"contract{rank}.txt")).read().splitlines()
+        assert "1 validation row(s) were given to a rank that does not own" in stray
+        assert "training row(s) lie outside their rank's user range" in bad

@@ -1,5 +1,7 @@
 """A short randomised parity sweep (tests/fuzz_parity.py): all five CAVI models through the model classes, f64 and
 f32, on small random problems with odd shapes, against the CPU oracle."""
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -21,3 +23,30 @@ def test_random_problems_through_the_three_stage_path(capsys):
     failures, worst = fuzz_parity.sweep_three_stage(80, seed=3, quiet=True)
     assert failures == 0, capsys.readouterr().out
     assert worst <= 2e-4
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_random_problems_sharded_over_ranks_match_one_context(world, tmp_path):
+    """Sharded fits (hostshm ranks on the one GPU; full-frame and presharded; random item row chunks) of random
+    small problems against the single-context fit of the same model: tests/fuzz_sharded.py."""
+    import multiprocessing as mp
+    import socket
+    import fuzz_sharded
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sweep")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=fuzz_sharded.worker, args=(r, world, port, 40, 100 + world, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(400)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+        p.join()
+    logs = "\n".join(open(f"{out}.rank{r}").read() for r in range(world) if os.path.exists(f"{out}.rank{r}"))
+    assert not hung, "a rank hung\n" + logs
+    assert [p.exitcode for p in procs] == [0] * world, logs
+    assert logs.count("done 40 0 ") == world, logs

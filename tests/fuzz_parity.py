@@ -97,6 +97,48 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
     both_nan = np.isnan(hv) & np.isnan(ov)
     if hv.size and not np.all(both_nan | (np.abs(hv - ov) <= 1e-6 * np.maximum(1.0, np.abs(ov)) + (0 if dtype == "f64" else 1e-3))):
         return float("inf"), f"val_rmse {hv} != {ov}"
+    # the fitted model's own API on fresh id lists (ids outside the trained range included)
+    tol_api = 1e-9 if dtype == "f64" else 2e-3
+    rng = np.random.default_rng(seed + 1)
+    U, I = int(np.max(u)) + 1, int(np.max(i)) + 1
+    qu, qi = rng.integers(0, U + 2, 25), rng.integers(0, I + 2, 25)
+    if kind == "poisson_ext":
+        want = orc.ext_predict(st, qu, qi)
+        got = m.predict(qu, qi)
+    elif kind.startswith("gauss"):
+        bias = kind == "gauss_bias"
+        want = orc.predict_dot(st["m_theta"], st["m_beta"], qu, qi, st["m_user_bias"] if bias else None,
+                               st["m_item_bias"] if bias else None, gm)
+        got = m.predict(qu, qi, gm)
+    else:
+        want = orc.predict_dot(st["E_theta"], st["E_beta"], qu, qi)
+        got = m.predict(qu, qi)
+    if got.shape != want.shape or not np.allclose(got, want, rtol=tol_api, atol=tol_api):
+        return float("inf"), f"predict {got} != {want}"
+    if kind != "poisson_ext":
+        if kind.startswith("gauss"):
+            e_want = orc.gaussian_eval(st, va[0], va[1], va[2], gm, bias=(kind == "gauss_bias"))
+            e_got = (m.evaluate_rmse(vdf, gm), m.evaluate_macro_mae(vdf, gm))
+        else:
+            e_want = orc.gamma_eval(st, *va)
+            e_got = (m.evaluate_rmse(vdf), m.evaluate_macro_mae(vdf))
+        for a, b in zip(e_got, e_want):
+            if not ((np.isnan(a) and np.isnan(b)) or abs(a - b) <= tol_api * max(1.0, abs(b))):
+                return float("inf"), f"evaluate {e_got} != {e_want}"
+    # top-k under the model's own score: every returned list must be a correct ranking of its own predictions
+    k = int(min(I, rng.integers(1, 8)))
+    users = rng.integers(0, U, 6)
+    items, scores = m.top_k_items(users, k)
+    every = np.arange(I)
+    for row, uu in enumerate(users):
+        full = m.predict(np.full(I, uu), every, gm) - gm if kind.startswith("gauss") else m.predict(np.full(I, uu), every)
+        order = np.lexsort((every, -full))[:k]
+        if not np.allclose(scores[row], full[items[row]], rtol=tol_api, atol=tol_api):
+            return float("inf"), f"top-k scores {scores[row]} vs predict {full[items[row]]}"
+        if not np.allclose(np.sort(full[items[row]])[::-1], full[order], rtol=10 * tol_api, atol=10 * tol_api):
+            return float("inf"), f"top-k of user {uu}: {items[row]} vs {order}"
+        if dtype == "f64" and len(set(np.round(full, 12))) == I and not np.array_equal(items[row], order):
+            return float("inf"), f"top-k order of user {uu}: {items[row]} vs {order}"
     if hasattr(m, "close"):
         m.close()
     return worst, ""

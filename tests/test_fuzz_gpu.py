@@ -50,3 +50,9 @@ def test_random_problems_sharded_over_ranks_match_one_context(world, tmp_path):
     assert not hung, "a rank hung\n" + logs
     assert [p.exitcode for p in procs] == [0] * world, logs
     assert logs.count("done 40 0 ") == world, logs
+
+
+def test_random_problems_graph_replay_is_bit_identical(capsys):
+    """PMF_HIP_GRAPH=1 (captured iteration, replayed) against the plain issue order."""
+    import fuzz_parity
+    assert fuzz_parity.sweep_graph(40, seed=4) == 0, capsys.readouterr().out

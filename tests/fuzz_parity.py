@@ -296,6 +296,47 @@ def sweep_graph(n_trials, seed):
     return bad
 
 
+def sweep_index(n_trials, seed):
+    """Device index build (radix sort + row pointers, pmf_index.hip) against the host counting sort
+    (PMF_INDEX_HOST=1) on random rating lists up to 60k entries: the fitted arrays must be bit-identical
+    (both builds are stable, so every row sums its ratings in the same order)."""
+    import fuzz_sharded
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for t in range(n_trials):
+        kind = str(rng.choice(["hpf", "gauss_bias"]))
+        U, I = int(rng.integers(1, 3000)), int(rng.integers(1, 800))
+        N = int(rng.integers(1, 60000))
+        u = rng.permutation(U)[np.floor(U * rng.random(N) ** 2.0).astype(np.int64)]
+        i = rng.permutation(I)[np.floor(I * rng.random(N) ** 3.0).astype(np.int64)]
+        x = rng.integers(0, 6, N).astype(np.float64)
+        K = int(rng.choice([3, 16, 40]))
+        train = pd.DataFrame({"u": u, "i": i, "rating": x})
+        gm = float(x.mean())
+        states = []
+        try:
+            for flag in (None, "1"):
+                if flag:
+                    os.environ["PMF_INDEX_HOST"] = flag
+                m = fuzz_sharded.build(kind, K, 3, 2)
+                if kind.startswith("gauss"):
+                    m.fit(train.assign(rating=train["rating"] - gm), global_mean=gm)
+                else:
+                    m.fit(train.assign(rating=train["rating"] + 1.0))
+                states.append([np.asarray(getattr(m, k)) for k in fuzz_sharded.KEYS[kind]])
+                m.close()
+            same = all(np.array_equal(a, b) for a, b in zip(*states))
+            msg = "" if same else "arrays differ"
+        except Exception as e:     # noqa: BLE001
+            same, msg = False, f"{type(e).__name__}: {e}"
+        finally:
+            os.environ.pop("PMF_INDEX_HOST", None)
+        if not same:
+            bad += 1
+            print(f"FAIL index trial {t}: {kind} K={K} U={U} I={I} N={N}: {msg}", flush=True)
+    return bad
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     failures, worst_by_kind = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -306,4 +347,6 @@ if __name__ == "__main__":
     print(f"three-stage path vs fused sweeps: {n // 2} trials, {f3} failures, worst f32 deviation {w3:.2e}")
     fg = sweep_graph(n // 4, 8)
     print(f"graph replay vs issued iterations: {n // 4} trials, {fg} failures")
-    sys.exit(1 if failures or f3 or fg else 0)
+    fi = sweep_index(n // 10, 9)
+    print(f"device index build vs host build: {n // 10} trials, {fi} failures")
+    sys.exit(1 if failures or f3 or fg or fi else 0)

@@ -62,7 +62,7 @@ SMALL = dict(U=100_000, I=10_000, N=5_000_000)  # --small: quick functional run
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD (= the fp32 vector peak)
 
 
-def topk_bench(args, local_rank):
+def topk_measure(args, local_rank, steps=None):
     """`--workload topk`: top-10 items of 100k for a batch of query users at K = 64 from
     the dense reconstruction Theta . Beta^T -- the one MFMA-bound kernel of the product.  A step = one
     pmf_topk_items call over the batch (ids in, ranked lists out: the host legs are inside the call, the roofline
@@ -83,27 +83,32 @@ def topk_bench(args, local_rank):
     ctx.prof_enable(True)
     ctx.prof_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    steps = steps or args.steps
+    for _ in range(steps):
         items, scores = ctx.topk_items(users, k)
     elapsed = time.perf_counter() - t0
     ms, launches = ctx.prof_get()["topk"]
-    flops = 2.0 * Q * I * K * args.steps
+    flops = 2.0 * Q * I * K * steps
     ach = flops / (ms * 1e-3) / 1e12
     # spot check against a NumPy ranking (exact fp32 tables, fp64 products)
     A, B = ctx.get_array(USER, ARR_FACTOR)[users[:64]], ctx.get_array(ITEM, ARR_FACTOR)
     want = np.argsort(-(A @ B.T), axis=1, kind="stable")[:, :k]
     agree = float(np.mean(items[:64] == want))
     ctx.close()
-    print(json.dumps({
-        "metric": f"query users/sec, top-{k} of {I} items from Theta.Beta^T, K={K}", "value": Q * args.steps / elapsed,
-        "unit": "users/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+    return {
+        "metric": f"query users/sec, top-{k} of {I} items from Theta.Beta^T, K={K}", "value": Q * steps / elapsed,
+        "unit": "users/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"top-{k} items for {Q} query users, {U}x{I} factors, K={K}" + (" [--small]" if args.small else ""),
-                   "kernel_users_per_s": Q * args.steps / (ms * 1e-3), "agreement_with_numpy_ranking": agree,
+                   "kernel_users_per_s": Q * steps / (ms * 1e-3), "agreement_with_numpy_ranking": agree,
                    "torch_imported": "torch" in sys.modules},
         "roofline": {"kernel": "topk_fused", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / max(launches, 1),
-                     "launches": launches}}), flush=True)
+                     "launches": launches}}
+
+
+def topk_bench(args, local_rank):
+    print(json.dumps(topk_measure(args, local_rank)), flush=True)
 
 
 def algorithmic_bytes(workload, U, I, N, K, elem=4):
@@ -521,6 +526,11 @@ def main():
             also["f64"] = {"gaussian_mf": run("gaussian_mf", hp, 3, 1, "f64"),
                            "hpf_cavi": run("hpf_cavi", WORKLOADS["hpf_cavi"]["hp"], 5, 1, "f64")}
     del u, i, r
+    if also and comm is None and args.dtype == "f32" and not args.factors:
+        # the one MFMA-bound kernel of the product, same line as `--workload topk`
+        t = topk_measure(args, local_rank, steps=3)
+        also["topk"] = {key: t[key] for key in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline")}
+        also["topk"]["config"] = t["config"]
 
     if rank != 0:
         comm.barrier()
@@ -574,6 +584,8 @@ def main():
         out["also"] = {}
         if "hpf_cavi" in also:
             out["also"]["hpf_cavi"] = brief(also["hpf_cavi"], f"ratings/sec (epoch) HPF-CAVI K={K}", args.dtype)
+        if "topk" in also:
+            out["also"]["topk"] = also["topk"]
         if "f64" in also:
             out["also"]["f64"] = {"gaussian_mf": brief(also["f64"]["gaussian_mf"], f"ratings/sec (epoch) Gaussian-MF K={K}", "f64"),
                                   "hpf_cavi": brief(also["f64"]["hpf_cavi"], f"ratings/sec (epoch) HPF-CAVI K={K}", "f64")}

@@ -259,6 +259,11 @@ int pmf_comm_init_hostshm(pmf_ctx *ctx, int nranks, int rank, const void *unique
 int pmf_comm_attach(pmf_ctx *ctx, pmf_ctx *owner);
 int pmf_comm_destroy(pmf_ctx *ctx);
 int pmf_comm_info(pmf_ctx *ctx, int *nranks, int *rank, int *transport);
+/* Waiting under a communicator: pmf_ctx_sync (of a context with a communicator), pmf_comm_barrier,
+ * pmf_comm_allreduce_host and pmf_comm_gather_user_rows poll the stream, the communicator's asynchronous error
+ * state and a deadline (environment PMF_COMM_TIMEOUT_S, seconds, default 1800, 0 = none).  When a peer died or
+ * never reached its collective they abort the communicator and return PMF_ECOMM; every later collective call on
+ * it returns PMF_ECOMM at once. */
 /* all queued work of every rank (kernels and collectives) has finished when this returns */
 int pmf_comm_barrier(pmf_ctx *ctx);
 /* element-wise sum / max of n host doubles over the ranks, result on every rank (validation sums of

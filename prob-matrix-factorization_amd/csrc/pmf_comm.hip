@@ -70,6 +70,8 @@ struct PmfComm {
     std::vector<hipEvent_t> ev_ready, ev_done, ev_fin;  // per row chunk: statistics ready / all-reduced / finalized
     void *d_small = nullptr;                  // kSmallBytes, host-value collectives
     void *h_small = nullptr;                  // pinned twin
+    bool failed = false;                      // a collective failed or timed out: every later call returns PMF_ECOMM
+    double timeout_s = 1800.0;                // PMF_COMM_TIMEOUT_S
     // HOSTSHM
     char shm_name[64] = "";
     void *shm = nullptr;
@@ -100,7 +102,7 @@ bool shm_barrier(PmfComm *cm) {
     while (h->generation.load() == gen) {
         if (h->failed.load()) return false;
         if ((++spins & 1023) == 0) {
-            if (now_s() - t0 > kShmTimeoutS) {
+            if (now_s() - t0 > (cm->timeout_s > 0 ? std::min(kShmTimeoutS, cm->timeout_s) : kShmTimeoutS)) {
                 h->failed.store(1);
                 return false;
             }
@@ -222,8 +224,52 @@ int shm_open_region(PmfComm *cm, const void *unique_id) {
 // ---------------------------------------------------------------------------
 // transport-independent primitives (all asynchronous on cm->stream)
 // ---------------------------------------------------------------------------
+// Wait for `stream` while watching the communicator: RCCL reports a dead peer / a failed link through
+// ncclCommGetAsyncError, and a rank that never reaches its collective shows up only as time passing.
+int comm_wait(PmfComm *cm, hipStream_t stream, const char *what) {
+    const double t0 = now_s();
+    for (unsigned spins = 0;; ++spins) {
+        hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            pmf_set_error("%s: hipStreamQuery failed: %s", what, hipGetErrorString(q));
+            return PMF_EHIP;
+        }
+        if (spins < 2000) continue;            // short waits (the small host collectives) stay on the fast path
+        if (cm->nccl) {
+            ncclResult_t async = ncclSuccess;
+            if (ncclCommGetAsyncError(cm->nccl, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                cm->failed = true;
+                pmf_set_error("%s: the communicator reported %s (rank %d of %d); aborting it", what,
+                              ncclGetErrorString(async), cm->rank, cm->nranks);
+                (void)ncclCommAbort(cm->nccl);
+                cm->nccl = nullptr;
+                return PMF_ECOMM;
+            }
+        }
+        if (cm->transport == PMF_TRANSPORT_HOSTSHM && cm->hdr()->failed.load()) {
+            cm->failed = true;
+            pmf_set_error("%s: hostshm transport: a peer failed or timed out", what);
+            return PMF_ECOMM;
+        }
+        if (cm->timeout_s > 0 && now_s() - t0 > cm->timeout_s) {
+            cm->failed = true;
+            pmf_set_error("%s: no progress for %.0f s (rank %d of %d; PMF_COMM_TIMEOUT_S) -- a peer died or never reached "
+                          "its collective", what, cm->timeout_s, cm->rank, cm->nranks);
+            if (cm->nccl) {
+                (void)ncclCommAbort(cm->nccl);
+                cm->nccl = nullptr;
+            }
+            return PMF_ECOMM;
+        }
+        usleep(spins < 20000 ? 20 : 500);
+    }
+    return PMF_OK;
+}
+
 int comm_allreduce(PmfComm *cm, void *buf, size_t count, int dtype, int op) {
     if (count == 0) return PMF_OK;
+    PMF_REQUIRE(!cm->failed, PMF_ECOMM, "the communicator has failed earlier (a collective error or timeout)");
     if (cm->transport == PMF_TRANSPORT_HOSTSHM)
         return shm_collective(cm, buf, buf, count * (dtype == PMF_F64 ? 8 : 4), dtype, op, 0);
     PMF_NCCL_CHECK(ncclAllReduce(buf, buf, count, dtype == PMF_F64 ? ncclFloat64 : ncclFloat32,
@@ -233,6 +279,7 @@ int comm_allreduce(PmfComm *cm, void *buf, size_t count, int dtype, int op) {
 
 int comm_broadcast(PmfComm *cm, const void *send, void *recv, size_t bytes, int root) {
     if (bytes == 0) return PMF_OK;
+    PMF_REQUIRE(!cm->failed, PMF_ECOMM, "the communicator has failed earlier (a collective error or timeout)");
     if (cm->transport == PMF_TRANSPORT_HOSTSHM) return shm_collective(cm, send, recv, bytes, -1, 0, root);
     PMF_NCCL_CHECK(ncclBroadcast(send, recv, bytes, ncclInt8, root, cm->nccl, cm->stream));
     return PMF_OK;
@@ -273,6 +320,7 @@ int comm_create(pmf_ctx *ctx, int nranks, int rank, const void *unique_id, int t
     cm->rank = rank;
     cm->device = ctx->device;
     cm->transport = transport;
+    if (const char *e = getenv("PMF_COMM_TIMEOUT_S")) cm->timeout_s = atof(e);
     int rc = PMF_OK;
     do {
         int lo = 0, hi = 0;   // collectives must not queue behind a 60 ms accumulate grid
@@ -345,6 +393,8 @@ int ensure_events(PmfComm *cm, size_t n) {
 // then RCCL's identity): callers attach one only for multi-rank runs, and the one-GPU tests can drive
 // the real RCCL call sequence.
 bool pmf_comm_active(const pmf_ctx *ctx) { return ctx->comm != nullptr; }
+
+int pmf_comm_wait_stream(pmf_ctx *ctx, hipStream_t stream, const char *what) { return comm_wait(ctx->comm, stream, what); }
 
 void pmf_comm_release(pmf_ctx *ctx) {
     for (int k = 0; k < 2; ++k) {
@@ -515,7 +565,7 @@ extern "C" int pmf_comm_allreduce_host(pmf_ctx *ctx, double *values, int64_t n, 
         int rc = comm_allreduce(cm, cm->d_small, (size_t)m, PMF_F64, op);
         if (rc) return rc;
         PMF_HIP_CHECK(hipMemcpyAsync(cm->h_small, cm->d_small, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, cm->stream));
-        PMF_HIP_CHECK(hipStreamSynchronize(cm->stream));
+        if ((rc = comm_wait(cm, cm->stream, "pmf_comm_allreduce_host"))) return rc;
         PMF_REQUIRE(cm->transport != PMF_TRANSPORT_HOSTSHM || !cm->hdr()->failed.load(), PMF_ECOMM,
                     "hostshm transport: a peer failed or timed out");
         memcpy(values + at, cm->h_small, (size_t)m * sizeof(double));
@@ -527,6 +577,12 @@ extern "C" int pmf_comm_allreduce_host(pmf_ctx *ctx, double *values, int64_t n, 
 extern "C" int pmf_comm_barrier(pmf_ctx *ctx) {
     PMF_REQUIRE(ctx != nullptr, PMF_EINVAL, "pmf_comm_barrier: null context");
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->comm) {   // the streams that can be stuck behind a collective are waited for under the watchdog first
+        int rc;
+        if ((rc = comm_wait(ctx->comm, ctx->stream, "pmf_comm_barrier"))) return rc;
+        if ((rc = comm_wait(ctx->comm, ctx->comm->stream, "pmf_comm_barrier"))) return rc;
+        if ((rc = comm_wait(ctx->comm, ctx->comm->fin_stream, "pmf_comm_barrier"))) return rc;
+    }
     PMF_HIP_CHECK(hipDeviceSynchronize());   // every stream of this process on the device, other contexts' included
     if (!ctx->comm) return PMF_OK;
     double one = 1.0;
@@ -568,7 +624,7 @@ extern "C" int pmf_comm_gather_user_rows(pmf_ctx *ctx, int array, const int64_t 
                                             : (const char *)ctx->d_scratch;
             if ((rc = comm_broadcast(cm, src, ctx->d_scratch, bytes, r))) return rc;
             PMF_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, cm->stream));
-            PMF_HIP_CHECK(hipStreamSynchronize(cm->stream));
+            if ((rc = comm_wait(cm, cm->stream, "pmf_comm_gather_user_rows"))) return rc;
             pmf_unpack_rows(ctx, array, ctx->h_pinned, host_full + (bounds[r] + r0) * width, nr);
         }
     }

@@ -343,6 +343,7 @@ extern "C" int pmf_graph_destroy(pmf_ctx *ctx, int graph_id) {
 extern "C" int pmf_ctx_sync(pmf_ctx *ctx) {
     CHECK_CTX(ctx, "pmf_ctx_sync");
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
+    if (pmf_comm_active(ctx)) return pmf_comm_wait_stream(ctx, ctx->stream, "pmf_ctx_sync");   // (watches the peers too)
     PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return PMF_OK;
 }

@@ -198,6 +198,10 @@ void pmf_unpack_rows(const pmf_ctx *ctx, int array, const void *src, double *dst
 bool pmf_comm_active(const pmf_ctx *ctx);
 void pmf_comm_release(pmf_ctx *ctx);   // detach + free the statistics buffers (pmf_ctx_destroy)
 int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out);
+// hipStreamSynchronize for a context with a communicator: polls the stream, RCCL's asynchronous error state and
+// a deadline (PMF_COMM_TIMEOUT_S, default 1800; 0 = wait for ever), so that a peer that died or never arrived
+// ends in PMF_ECOMM on the surviving ranks instead of a hang.
+int pmf_comm_wait_stream(pmf_ctx *ctx, hipStream_t stream, const char *what);
 int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool chunked,
                         const std::function<int()> &accumulate, const std::function<int()> &finalize);
 

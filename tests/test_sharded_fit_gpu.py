@@ -327,3 +327,51 @@ def test_comm_error_paths():
         a.comm_barrier()   # without a communicator: a device sync
     finally:
         a.close(); b.close()
+
+
+def _watchdog_worker(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", PMF_COMM_TRANSPORT="hostshm", PMF_COMM_TIMEOUT_S="3")
+    import time
+    import pmf_hip
+    from pmf_hip import dist as pdist
+    comm = pdist.init_from_env(device=0)            # both ranks arrive here (the init ends in a barrier)
+    if rank == 1:
+        os._exit(0)                                  # this rank dies before its next collective
+    t0 = time.time()
+    try:
+        comm.barrier()
+        verdict = "returned"
+    except pmf_hip.PmfError as e:
+        verdict = f"{time.time() - t0:.1f} {e}"
+    try:                                             # and the communicator stays failed instead of hanging later
+        comm.all_reduce_host([1.0])
+        verdict += " | second call returned"
+    except pmf_hip.PmfError as e:
+        verdict += f" | {e}"
+    with open(os.path.join(out_dir, "watchdog.txt"), "w") as fh:
+        fh.write(verdict)
+    os._exit(0)
+
+
+def test_a_dead_peer_ends_in_an_error_not_a_hang(tmp_path):
+    """PMF_COMM_TIMEOUT_S: a rank whose peer died before the next collective gets PMF_ECOMM from the wait
+    (stream + communicator watchdog) within the deadline, and every later collective call fails at once."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_watchdog_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+        p.join()
+    assert not hung, "the surviving rank hung"
+    verdict = open(os.path.join(tmp_path, "watchdog.txt")).read()
+    seconds = float(verdict.split()[0])
+    assert 2.0 <= seconds <= 30.0, verdict
+    assert "pmf_comm_barrier failed (-5)" in verdict and ("no progress" in verdict or "peer failed" in verdict), verdict
+    assert "has failed earlier" in verdict.split("|")[1] or "peer failed" in verdict.split("|")[1], verdict

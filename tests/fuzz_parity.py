@@ -21,6 +21,7 @@ KEYS = {
                     "E_phi", "E_psi"],
     "gauss_bias": ["m_theta", "m_beta", "V_theta", "V_beta", "m_user_bias", "m_item_bias"],
     "gauss": ["m_theta", "m_beta", "V_theta", "V_beta"],
+    "sgd": ["m_theta", "m_beta", "m_user_bias", "m_item_bias"],     # gradient mode: no reference counterpart, own oracle
 }
 
 
@@ -64,6 +65,13 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
         cfg = dict(n_factors=K, a0=0.2, b0=0.6, max_iter=iters, tol=None, random_state=seed)
         train["rating"] += 1; vdf["rating"] += 1
         m = PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(verbose=False, **cfg), dtype=dtype)
+    elif kind == "sgd":
+        from src.models.gaussian_mf_sgd import GaussianMFSGD, GaussianMFSGDConfig
+        cfg = dict(n_factors=K, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, eta_bias2=1.3, lr=0.02, max_iter=iters, tol=-1e9,
+                   random_state=seed)
+        gm = float(train["rating"].mean())
+        train["rating"] -= gm; vdf["rating"] -= gm
+        m = GaussianMFSGD(GaussianMFSGDConfig(verbose=False, **cfg), dtype=dtype)
     else:
         cfg = dict(n_factors=K, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, max_iter=iters, tol=-1e9, random_state=seed)
         gm = float(train["rating"].mean())
@@ -75,11 +83,21 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
             m = gnb.GaussianMFCAVI(gnb.GaussianMFCAVIConfig(verbose=False, **cfg), dtype=dtype)
     tr = (train["u"].to_numpy(), train["i"].to_numpy(), train["rating"].to_numpy())
     va = (vdf["u"].to_numpy(), vdf["i"].to_numpy(), vdf["rating"].to_numpy())
-    if kind.startswith("gauss"):
+    if kind.startswith("gauss") or kind == "sgd":
         m.fit(train, vdf, global_mean=gm)
     else:
         m.fit(train, vdf)
-    st, hist = orc.fit(kind, *tr, cfg, val=va, global_mean=gm)
+    if kind == "sgd":
+        U_, I_ = orc.infer_dims(tr[0], tr[1])
+        st = orc.init_gaussian(U_, I_, K, seed, bias=True)
+        idx_ = (orc.group_positions(tr[0], U_), orc.group_positions(tr[1], I_))
+        hist = {"val_rmse": []}
+        for _ in range(iters):
+            orc.gauss_sgd_epoch(st, idx_, tr[0], tr[1], tr[2], cfg["lr"], cfg["sigma2"], cfg["eta_theta2"], cfg["eta_beta2"],
+                                cfg["eta_bias2"])
+            hist["val_rmse"].append(orc.gaussian_eval(st, va[0], va[1], va[2], gm, bias=True)[0])
+    else:
+        st, hist = orc.fit(kind, *tr, cfg, val=va, global_mean=gm)
     worst = 0.0
     for key in KEYS[kind]:
         got, want = np.asarray(getattr(m, key), dtype=np.float64), np.asarray(st[key], dtype=np.float64)
@@ -105,8 +123,8 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
     if kind == "poisson_ext":
         want = orc.ext_predict(st, qu, qi)
         got = m.predict(qu, qi)
-    elif kind.startswith("gauss"):
-        bias = kind == "gauss_bias"
+    elif kind.startswith("gauss") or kind == "sgd":
+        bias = kind != "gauss"
         want = orc.predict_dot(st["m_theta"], st["m_beta"], qu, qi, st["m_user_bias"] if bias else None,
                                st["m_item_bias"] if bias else None, gm)
         got = m.predict(qu, qi, gm)
@@ -116,8 +134,8 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
     if got.shape != want.shape or not np.allclose(got, want, rtol=tol_api, atol=tol_api):
         return float("inf"), f"predict {got} != {want}"
     if kind != "poisson_ext":
-        if kind.startswith("gauss"):
-            e_want = orc.gaussian_eval(st, va[0], va[1], va[2], gm, bias=(kind == "gauss_bias"))
+        if kind.startswith("gauss") or kind == "sgd":
+            e_want = orc.gaussian_eval(st, va[0], va[1], va[2], gm, bias=(kind != "gauss"))
             e_got = (m.evaluate_rmse(vdf, gm), m.evaluate_macro_mae(vdf, gm))
         else:
             e_want = orc.gamma_eval(st, *va)
@@ -131,7 +149,8 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
     items, scores = m.top_k_items(users, k)
     every = np.arange(I)
     for row, uu in enumerate(users):
-        full = m.predict(np.full(I, uu), every, gm) - gm if kind.startswith("gauss") else m.predict(np.full(I, uu), every)
+        full = m.predict(np.full(I, uu), every, gm) - gm if (kind.startswith("gauss") or kind == "sgd") \
+            else m.predict(np.full(I, uu), every)
         order = np.lexsort((every, -full))[:k]
         if not np.allclose(scores[row], full[items[row]], rtol=tol_api, atol=tol_api):
             return float("inf"), f"top-k scores {scores[row]} vs predict {full[items[row]]}"
@@ -153,7 +172,7 @@ def sweep(n_trials, seed, quiet=False):
         kind = str(rng.choice(list(KEYS)))
         dtype = str(rng.choice(["f64", "f64", "f32"]))
         K = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 24, 31, 32, 33, 40, 48, 49, 56, 57, 64, 65, 72, 80, 96, 100, 128, 130]))
-        if kind.startswith("gauss") and K > 64 and rng.random() < 0.5:
+        if (kind.startswith("gauss") or kind == "sgd") and K > 64 and rng.random() < 0.5:
             K = int(rng.integers(1, 64))              # keep most Gaussian cases cheap for the CPU oracle
         shape, u, i, x, val = problem(rng)
         seed, iters = int(rng.integers(0, 1000)), int(rng.integers(1, 4))

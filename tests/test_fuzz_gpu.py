@@ -9,10 +9,10 @@ pytestmark = pytest.mark.gpu
 
 def test_random_small_problems_match_the_oracle(capsys):
     import fuzz_parity
-    failures, worst = fuzz_parity.sweep(150, seed=20251226, quiet=True)
+    failures, worst = fuzz_parity.sweep(180, seed=20251226, quiet=True)
     out = capsys.readouterr().out
     assert failures == 0, out
-    assert len(worst) == 10                      # five kinds x two dtypes were all drawn
+    assert len(worst) == 12                      # six kinds x two dtypes were all drawn
     for (kind, dtype), err in worst.items():
         assert err <= (1e-12 if dtype == "f64" else 1e-4), (kind, dtype, err)
 

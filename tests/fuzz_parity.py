@@ -49,17 +49,17 @@ def problem(rng):
     return shape, u, i, x, (vu, vi, vx)
 
 
-def run(kind, dtype, u, i, x, val, K, seed, iters):
+def run(kind, dtype, u, i, x, val, K, seed, iters, tol_gamma=None, tol_gauss=-1e9):
     train = pd.DataFrame({"u": u, "i": i, "rating": x})
     vdf = pd.DataFrame({"u": val[0], "i": val[1], "rating": val[2]})
     gm = 0.0
     if kind == "hpf":
-        cfg = dict(n_factors=K, a=0.3, a_prime=2.0, b_prime=1.5, c=0.4, c_prime=3.0, d_prime=0.7, max_iter=iters, tol=None,
-                   random_state=seed)
+        cfg = dict(n_factors=K, a=0.3, a_prime=2.0, b_prime=1.5, c=0.4, c_prime=3.0, d_prime=0.7, max_iter=iters,
+                   tol=tol_gamma, random_state=seed)
         train["rating"] += 1; vdf["rating"] += 1
         m = HPF_CAVI(HPF_CAVI_Config(verbose=False, **cfg), dtype=dtype)
     elif kind == "poisson":
-        cfg = dict(n_factors=K, a0=0.2, b0=0.6, max_iter=iters, tol=None, random_state=seed)
+        cfg = dict(n_factors=K, a0=0.2, b0=0.6, max_iter=iters, tol=tol_gamma, random_state=seed)
         m = PoissonMFCAVI(PoissonMFCAVIConfig(verbose=False, **cfg), dtype=dtype)
     elif kind == "poisson_ext":
         cfg = dict(n_factors=K, a0=0.2, b0=0.6, max_iter=iters, tol=None, random_state=seed)
@@ -73,7 +73,7 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
         train["rating"] -= gm; vdf["rating"] -= gm
         m = GaussianMFSGD(GaussianMFSGDConfig(verbose=False, **cfg), dtype=dtype)
     else:
-        cfg = dict(n_factors=K, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, max_iter=iters, tol=-1e9, random_state=seed)
+        cfg = dict(n_factors=K, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, max_iter=iters, tol=tol_gauss, random_state=seed)
         gm = float(train["rating"].mean())
         train["rating"] -= gm; vdf["rating"] -= gm
         if kind == "gauss_bias":
@@ -108,6 +108,10 @@ def run(kind, dtype, u, i, x, val, K, seed, iters):
         if not np.isfinite(err):
             return float("inf"), f"{key}: non-finite"
         worst = max(worst, err)
+    if kind not in ("sgd", "poisson_ext") and (m.history_["iterations"], m.history_["stopped_early"]) != \
+            (hist["iterations"], hist["stopped_early"]):
+        return float("inf"), f"stopped after {m.history_['iterations']} ({m.history_['stopped_early']}), oracle after " \
+                             f"{hist['iterations']} ({hist['stopped_early']})"
     hv = np.asarray(m.history_["val_rmse"], dtype=np.float64)
     ov = np.asarray(hist["val_rmse"], dtype=np.float64)
     if hv.shape != ov.shape:
@@ -177,8 +181,13 @@ def sweep(n_trials, seed, quiet=False):
         shape, u, i, x, val = problem(rng)
         seed, iters = int(rng.integers(0, 1000)), int(rng.integers(1, 4))
         tol = 1e-9 if dtype == "f64" else 5e-3
+        tol_gamma, tol_gauss = None, -1e9
+        if dtype == "f64" and rng.random() < 0.5:       # the early-stop rules (f64: the decision cannot hinge on rounding)
+            iters = int(rng.integers(3, 8))
+            tol_gamma = float(rng.choice([1e-3, 0.02, 0.2]))
+            tol_gauss = float(rng.choice([1e-3, 0.02, -1.0]))
         try:
-            err, msg = run(kind, dtype, u, i, x, val, K, seed, iters)
+            err, msg = run(kind, dtype, u, i, x, val, K, seed, iters, tol_gamma, tol_gauss)
         except Exception as e:     # noqa: BLE001 -- the sweep reports and goes on
             err, msg = float("inf"), f"{type(e).__name__}: {e}"
         key = (kind, dtype)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
 
-This script is the only place in the repo that imports the reference
+This script and its sibling `live_reference.py` (the live-comparison helper of
+tests/test_live_reference_cpu.py) are the only places in the repo that import the reference
 (`/root/reference/src/models/*.py`).  It runs in the build container only --
 `/root/reference` does not exist on the GPU box -- and writes small `.npz`
 fixtures (inputs + expected outputs, no code) that pin

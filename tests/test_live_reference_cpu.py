@@ -1,0 +1,123 @@
+"""Random problems through the model classes' HOST logic against the reference itself, run live.
+
+Only in the build container: `/root/reference` does not exist on the GPU box, and nothing of it travels --
+`tests/golden/live_reference.py` runs the reference's classes in a subprocess (its `src` package and this repo's
+never share an interpreter) and hands back arrays and the captured stdout.  This side runs the SAME model classes
+the GPU uses, over the CPU stand-in of the engine (`tests/oracle_engine.py:OracleContext`), so what is compared is
+everything above the kernels: dimension inference, the RNG draw order of the initial state, the iteration order,
+the validation monitor, the early-stop rules, `predict` / `evaluate_*` semantics, and the verbose output --
+character for character."""
+import contextlib
+import io
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "models")),
+                                reason="the reference exists in the build container only")
+
+KEYS = {"hpf": ["gamma_a_theta", "gamma_b_theta", "gamma_a_beta", "gamma_b_beta", "E_theta", "E_beta", "E_xi", "E_eta"],
+        "poisson": ["a_theta", "b_theta", "a_beta", "b_beta", "E_theta", "E_beta"],
+        "gauss_bias": ["m_theta", "m_beta", "V_theta", "V_beta", "m_user_bias", "m_item_bias"],
+        "gauss": ["m_theta", "m_beta", "V_theta", "V_beta"]}
+
+
+def _config(kind, rng):
+    K = int(rng.choice([1, 2, 5, 8, 13]))
+    common = dict(n_factors=K, max_iter=int(rng.integers(1, 7)), random_state=int(rng.integers(0, 1000)), verbose=True)
+    if kind == "hpf":
+        return dict(common, a=0.3, a_prime=2.0, b_prime=1.5, c=0.4, c_prime=3.0, d_prime=0.7,
+                    tol=[None, 1e-3, 0.05][int(rng.integers(0, 3))])
+    if kind == "poisson":
+        return dict(common, a0=0.2, b0=0.6, tol=[None, 1e-3, 0.05][int(rng.integers(0, 3))])
+    cfg = dict(common, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, tol=[1e-3, 0.05, -1.0][int(rng.integers(0, 3))])
+    if kind == "gauss_bias":
+        cfg["eta_bias2"] = 1.3
+    return cfg
+
+
+def _build(kind, config):
+    if kind == "hpf":
+        from src.models.hpf_cavi import HPF_CAVI, HPF_CAVI_Config
+        return HPF_CAVI(HPF_CAVI_Config(**config), dtype="f64")
+    if kind == "poisson":
+        from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
+        return PoissonMFCAVI(PoissonMFCAVIConfig(**config), dtype="f64")
+    if kind == "gauss_bias":
+        from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
+        return GaussianMFCAVI(GaussianMFCAVIConfig(**config), dtype="f64")
+    from src.models.gaussian_mf_cavi import GaussianMFCAVI, GaussianMFCAVIConfig
+    return GaussianMFCAVI(GaussianMFCAVIConfig(**config), dtype="f64")
+
+
+def test_random_problems_host_logic_equals_the_live_reference(tmp_path, monkeypatch):
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import pmf_hip
+    from fuzz_parity import problem
+    from oracle_engine import OracleContext
+    rng = np.random.default_rng(20251226)
+    n_trials = 150
+    inputs, metas = {"n_trials": np.asarray(n_trials)}, []
+    for t in range(n_trials):
+        kind = str(rng.choice(list(KEYS)))
+        shape, u, i, x, (vu, vi, vx) = problem(rng)
+        gauss = kind.startswith("gauss")
+        gm = float(x.mean()) if gauss else 0.0
+        shift = -gm if gauss else (1.0 if kind == "hpf" else 0.0)          # the drivers' preprocessing
+        U, I = int(u.max()) + 1, int(i.max()) + 1
+        meta = {"kind": kind, "config": _config(kind, rng), "global_mean": gm, "validate": bool(rng.random() < 0.8)}
+        metas.append((meta, shape))
+        inputs.update({f"t{t}_u": u, f"t{t}_i": i, f"t{t}_x": x + shift, f"t{t}_vu": vu, f"t{t}_vi": vi, f"t{t}_vx": vx + shift,
+                       f"t{t}_qu": rng.integers(0, U + 2, 20), f"t{t}_qi": rng.integers(0, I + 2, 20),
+                       f"t{t}_cfg": np.asarray(json.dumps(meta))})
+    src, dst = str(tmp_path / "problems.npz"), str(tmp_path / "reference_out.npz")
+    np.savez(src, **inputs)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference.py"), src, dst], env=env,
+                          capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert done.returncode == 0, done.stderr[-2000:]
+    ref = np.load(dst, allow_pickle=False)
+
+    monkeypatch.setattr(pmf_hip, "Context", OracleContext)      # the model classes look the context class up at run time
+    seen = {"validated": 0, "stopped_early": 0, "warned": 0, "kinds": set()}
+    for t, (meta, shape) in enumerate(metas):
+        kind, gm = meta["kind"], meta["global_mean"]
+        gauss = kind.startswith("gauss")
+        tag = f"trial {t}: {kind} {shape} {meta['config']} validate={meta['validate']}"
+        train = pd.DataFrame({"u": inputs[f"t{t}_u"], "i": inputs[f"t{t}_i"], "rating": inputs[f"t{t}_x"]})
+        vdf = pd.DataFrame({"u": inputs[f"t{t}_vu"], "i": inputs[f"t{t}_vi"], "rating": inputs[f"t{t}_vx"]})
+        val = vdf if meta["validate"] else None
+        model = _build(kind, meta["config"])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            if gauss:
+                model.fit(train, val_df=val, global_mean=gm)
+            else:
+                model.fit(train, val_df=val)
+        assert buf.getvalue() == str(ref[f"t{t}_stdout"]), tag
+        seen["kinds"].add(kind)
+        seen["validated"] += "Validation RMSE" in buf.getvalue()
+        seen["stopped_early"] += model.history_["stopped_early"]
+        seen["warned"] += "Warning" in buf.getvalue()
+        for k in KEYS[kind]:
+            np.testing.assert_allclose(np.asarray(getattr(model, k)), ref[f"t{t}_{k}"], rtol=1e-9, atol=1e-12, err_msg=f"{tag}: {k}")
+        qu, qi = inputs[f"t{t}_qu"], inputs[f"t{t}_qi"]
+        got = model.predict(qu, qi, gm) if gauss else model.predict(qu, qi)
+        np.testing.assert_allclose(got, ref[f"t{t}_predict"], rtol=1e-9, atol=1e-12, err_msg=tag)
+        ebuf = io.StringIO()
+        want_ev = ref[f"t{t}_evaluate"]
+        with contextlib.redirect_stdout(ebuf), np.errstate(all="ignore"):
+            ev = [model.evaluate_rmse(vdf, gm) if gauss else model.evaluate_rmse(vdf)]
+            if len(want_ev) == 2:      # (the reference's bias-free Gaussian class has no MacroMAE method)
+                ev.append(model.evaluate_macro_mae(vdf, gm) if gauss else model.evaluate_macro_mae(vdf))
+        np.testing.assert_allclose(np.asarray(ev, dtype=np.float64), want_ev, rtol=1e-9, equal_nan=True, err_msg=tag)
+        assert ebuf.getvalue() == str(ref[f"t{t}_eval_stdout"]), tag
+    # the sweep really went through the interesting branches
+    assert seen["kinds"] == set(KEYS) and seen["validated"] >= 80 and seen["stopped_early"] >= 10, seen

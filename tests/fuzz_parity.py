@@ -365,6 +365,63 @@ def sweep_index(n_trials, seed):
     return bad
 
 
+def sweep_medium(n_trials, seed):
+    """Medium problems -- 2.2M to 9M ratings, where the work lists use 64-, 128- and 256-rating tasks (the small
+    sweeps above see 32, the full-size tests 512) -- against the oracle's vectorised form: direct C-ABI sweeps,
+    one iteration, f64.  Returns (failures, worst deviation)."""
+    import pmf_hip
+    from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ARR_PRIOR_RATE, ARR_RATE, ARR_SHAPE, ITEM, USER
+    rng = np.random.default_rng(seed)
+    bad, worst = 0, 0.0
+    for t in range(n_trials):
+        kind = "gauss" if t % 3 == 2 else "hpf"
+        N = int(rng.integers(2_200_000, 9_000_000)) if kind == "hpf" else int(rng.integers(2_200_000, 4_000_000))
+        U, I = int(rng.integers(20_000, 200_000)), int(rng.integers(500, 20_000))
+        K = int(rng.choice([4, 12, 16])) if kind == "hpf" else int(rng.choice([4, 8]))
+        u = rng.permutation(U)[np.floor(U * rng.random(N) ** 2.0).astype(np.int64)]
+        i = rng.permutation(I)[np.floor(I * rng.random(N) ** 3.0).astype(np.int64)]
+        u[0], i[0] = U - 1, I - 1
+        x = rng.integers(0, 6, N).astype(np.float64)
+        idx = (orc.group_positions(u, U), orc.group_positions(i, I))
+        try:
+            with pmf_hip.Context(U, I, K, dtype="f64") as ctx:
+                if kind == "hpf":
+                    st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, seed=3)
+                    ctx.set_ratings(u, i, x + 1.0)
+                    ctx.set_array(USER, ARR_FACTOR, st["E_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["E_beta"])
+                    ctx.set_array(USER, ARR_PRIOR_RATE, st["E_xi"]); ctx.set_array(ITEM, ARR_PRIOR_RATE, st["E_eta"])
+                    orc.hpf_iteration(st, idx, u, i, x + 1.0, 0.3, 5.0, 0.3, 5.0, orc.gamma_half_sweep_segsum)
+                    ctx.gamma_sweep(USER, 0.3, 0.0, True, st["gamma_a_xi"], 5.0)
+                    ctx.gamma_sweep(ITEM, 0.3, 0.0, True, st["gamma_a_eta"], 5.0)
+                    pairs = [("gamma_a_theta", USER, ARR_SHAPE), ("gamma_b_theta", USER, ARR_RATE), ("gamma_a_beta", ITEM, ARR_SHAPE),
+                             ("gamma_b_beta", ITEM, ARR_RATE), ("E_theta", USER, ARR_FACTOR), ("E_beta", ITEM, ARR_FACTOR)]
+                else:
+                    st = orc.init_gaussian(U, I, K, 5, bias=True)
+                    xc = x - x.mean()
+                    ctx.set_ratings(u, i, xc)
+                    ctx.set_array(USER, ARR_FACTOR, st["m_theta"]); ctx.set_array(ITEM, ARR_FACTOR, st["m_beta"])
+                    ctx.set_cov_identity(USER); ctx.set_cov_identity(ITEM)
+                    ctx.set_array(USER, ARR_BIAS, np.zeros(U)); ctx.set_array(ITEM, ARR_BIAS, np.zeros(I))
+                    orc.gaussian_iteration(st, idx, u, i, xc, 0.4, 0.6, 0.9, 1.3, True)
+                    ctx.gauss_factor_sweep(USER, 0.4, 0.6); ctx.gauss_factor_sweep(ITEM, 0.4, 0.9)
+                    ctx.gauss_bias_sweep(USER, 0.4, 1.3); ctx.gauss_bias_sweep(ITEM, 0.4, 1.3)
+                    pairs = [("m_theta", USER, ARR_FACTOR), ("m_beta", ITEM, ARR_FACTOR), ("V_theta", USER, ARR_COV),
+                             ("V_beta", ITEM, ARR_COV), ("m_user_bias", USER, ARR_BIAS), ("m_item_bias", ITEM, ARR_BIAS)]
+                err = 0.0
+                for key, side, arr in pairs:
+                    got, want = ctx.get_array(side, arr), st[key]
+                    err = max(err, float(np.max(np.abs(got - want)) / max(1.0, float(np.max(np.abs(want))))))
+            msg = ""
+        except Exception as e:     # noqa: BLE001
+            err, msg = float("inf"), f"{type(e).__name__}: {e}"
+        if err <= 1e-9:
+            worst = max(worst, err)
+        else:
+            bad += 1
+            print(f"FAIL medium trial {t}: {kind} K={K} U={U} I={I} N={N}: err={err:.3e} {msg}", flush=True)
+    return bad, worst
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     failures, worst_by_kind = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -368,7 +368,7 @@ def sweep_index(n_trials, seed):
 def sweep_medium(n_trials, seed):
     """Medium problems -- 2.2M to 9M ratings, where the work lists use 64-, 128- and 256-rating tasks (the small
     sweeps above see 32, the full-size tests 512) -- against the oracle's vectorised form: direct C-ABI sweeps,
-    one iteration, f64.  Returns (failures, worst deviation)."""
+    one iteration, f64 and f32.  Returns (failures, worst f64 deviation)."""
     import pmf_hip
     from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ARR_PRIOR_RATE, ARR_RATE, ARR_SHAPE, ITEM, USER
     rng = np.random.default_rng(seed)
@@ -377,14 +377,15 @@ def sweep_medium(n_trials, seed):
         kind = "gauss" if t % 3 == 2 else "hpf"
         N = int(rng.integers(2_200_000, 9_000_000)) if kind == "hpf" else int(rng.integers(2_200_000, 4_000_000))
         U, I = int(rng.integers(20_000, 200_000)), int(rng.integers(500, 20_000))
-        K = int(rng.choice([4, 12, 16])) if kind == "hpf" else int(rng.choice([4, 8]))
+        K = int(rng.choice([4, 12, 16, 32])) if kind == "hpf" else int(rng.choice([4, 8, 16]))
+        dtype = str(rng.choice(["f64", "f32"]))
         u = rng.permutation(U)[np.floor(U * rng.random(N) ** 2.0).astype(np.int64)]
         i = rng.permutation(I)[np.floor(I * rng.random(N) ** 3.0).astype(np.int64)]
         u[0], i[0] = U - 1, I - 1
         x = rng.integers(0, 6, N).astype(np.float64)
         idx = (orc.group_positions(u, U), orc.group_positions(i, I))
         try:
-            with pmf_hip.Context(U, I, K, dtype="f64") as ctx:
+            with pmf_hip.Context(U, I, K, dtype=dtype) as ctx:
                 if kind == "hpf":
                     st = orc.init_hpf(U, I, K, 0.3, 5.0, 5.0, 0.3, 5.0, 5.0, seed=3)
                     ctx.set_ratings(u, i, x + 1.0)
@@ -414,11 +415,11 @@ def sweep_medium(n_trials, seed):
             msg = ""
         except Exception as e:     # noqa: BLE001
             err, msg = float("inf"), f"{type(e).__name__}: {e}"
-        if err <= 1e-9:
-            worst = max(worst, err)
+        if err <= (1e-9 if dtype == "f64" else 5e-4):
+            worst = max(worst, err) if dtype == "f64" else worst
         else:
             bad += 1
-            print(f"FAIL medium trial {t}: {kind} K={K} U={U} I={I} N={N}: err={err:.3e} {msg}", flush=True)
+            print(f"FAIL medium trial {t}: {kind} {dtype} K={K} U={U} I={I} N={N}: err={err:.3e} {msg}", flush=True)
     return bad, worst
 
 

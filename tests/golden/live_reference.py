@@ -22,10 +22,14 @@ from src.models.gaussian_mf_cavi import GaussianMFCAVI as Gauss, GaussianMFCAVIC
 from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI as GaussBias, GaussianMFCAVIConfig as GaussBiasCfg  # noqa: E402
 from src.models.hpf_cavi import HPF_CAVI, HPF_CAVI_Config  # noqa: E402
 from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig  # noqa: E402
+from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVI, PoissonMFExtendedCAVIConfig  # noqa: E402
 
 KINDS = {"hpf": (HPF_CAVI, HPF_CAVI_Config, ["gamma_a_theta", "gamma_b_theta", "gamma_a_beta", "gamma_b_beta", "E_theta",
                                              "E_beta", "E_xi", "E_eta"]),
          "poisson": (PoissonMFCAVI, PoissonMFCAVIConfig, ["a_theta", "b_theta", "a_beta", "b_beta", "E_theta", "E_beta"]),
+         "poisson_ext": (PoissonMFExtendedCAVI, PoissonMFExtendedCAVIConfig,
+                         ["a_theta", "b_theta", "a_beta", "b_beta", "a_phi", "b_phi", "a_psi", "b_psi", "E_theta", "E_beta", "E_phi",
+                          "E_psi"]),
          "gauss_bias": (GaussBias, GaussBiasCfg, ["m_theta", "m_beta", "V_theta", "V_beta", "m_user_bias", "m_item_bias"]),
          "gauss": (Gauss, GaussCfg, ["m_theta", "m_beta", "V_theta", "V_beta"])}
 

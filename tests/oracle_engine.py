@@ -332,6 +332,18 @@ class OracleContext(OracleEngine):
                 OracleEngine.gamma_sweep(self, side, *prior)
         self._with("gamma", run)
 
+    def gamma_ext_sweep(self, side, a0, b0):
+        """pmf_gamma_ext_sweep (single context only, as in the library): arrays 0 / 1 / 2 = E / shape / rate of
+        the factors, 7 / 8 / 9 = E / shape / rate of the scalar scale."""
+        assert self._comm is None
+        other = ITEM if side == USER else USER
+        ptr, pos = self.idx[0] if side == USER else self.idx[1]
+        oid = self.i if side == USER else self.u
+        a, b, E, sa, sb, S = orc.gamma_ext_half_sweep_rows(self.raw[(side, 0)], self.raw[(side, 7)], self.raw[(other, 0)],
+                                                           self.raw[(other, 7)], ptr, pos, oid, self.x, a0, b0)
+        for array, value in ((1, a), (2, b), (0, E), (8, sa), (9, sb), (7, S)):
+            self.raw[(side, array)] = value
+
     def gauss_factor_sweep(self, side, sigma2, eta2):
         def run():
             if side == ITEM and self._comm is not None:
@@ -361,7 +373,9 @@ class OracleContext(OracleEngine):
         out = np.zeros(len(u))
         A, B = self.raw[(USER, 0)], self.raw[(ITEM, 0)]
         out[ok] = np.einsum("nk,nk->n", A[u[ok]], B[i[ok]])
-        if use_bias:
+        if use_bias == 2:      # PREDICT_SCALE: the extended Poisson model's phi_u psi_i theta_u.beta_i
+            out[ok] *= self.raw[(USER, 7)][u[ok]] * self.raw[(ITEM, 7)][i[ok]]
+        elif use_bias:
             out[ok] += self.raw[(USER, 6)][u[ok]] + self.raw[(ITEM, 6)][i[ok]]
         return out + offset
 

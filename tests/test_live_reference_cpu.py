@@ -25,6 +25,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "mode
 
 KEYS = {"hpf": ["gamma_a_theta", "gamma_b_theta", "gamma_a_beta", "gamma_b_beta", "E_theta", "E_beta", "E_xi", "E_eta"],
         "poisson": ["a_theta", "b_theta", "a_beta", "b_beta", "E_theta", "E_beta"],
+        "poisson_ext": ["a_theta", "b_theta", "a_beta", "b_beta", "a_phi", "b_phi", "a_psi", "b_psi", "E_theta", "E_beta",
+                        "E_phi", "E_psi"],
         "gauss_bias": ["m_theta", "m_beta", "V_theta", "V_beta", "m_user_bias", "m_item_bias"],
         "gauss": ["m_theta", "m_beta", "V_theta", "V_beta"]}
 
@@ -35,7 +37,7 @@ def _config(kind, rng):
     if kind == "hpf":
         return dict(common, a=0.3, a_prime=2.0, b_prime=1.5, c=0.4, c_prime=3.0, d_prime=0.7,
                     tol=[None, 1e-3, 0.05][int(rng.integers(0, 3))])
-    if kind == "poisson":
+    if kind in ("poisson", "poisson_ext"):
         return dict(common, a0=0.2, b0=0.6, tol=[None, 1e-3, 0.05][int(rng.integers(0, 3))])
     cfg = dict(common, sigma2=0.4, eta_theta2=0.6, eta_beta2=0.9, tol=[1e-3, 0.05, -1.0][int(rng.integers(0, 3))])
     if kind == "gauss_bias":
@@ -50,6 +52,9 @@ def _build(kind, config):
     if kind == "poisson":
         from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
         return PoissonMFCAVI(PoissonMFCAVIConfig(**config), dtype="f64")
+    if kind == "poisson_ext":
+        from src.models.poisson_mf_extended_cavi import PoissonMFExtendedCAVI, PoissonMFExtendedCAVIConfig
+        return PoissonMFExtendedCAVI(PoissonMFExtendedCAVIConfig(**config), dtype="f64")
     if kind == "gauss_bias":
         from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
         return GaussianMFCAVI(GaussianMFCAVIConfig(**config), dtype="f64")
@@ -70,7 +75,7 @@ def test_random_problems_host_logic_equals_the_live_reference(tmp_path, monkeypa
         shape, u, i, x, (vu, vi, vx) = problem(rng)
         gauss = kind.startswith("gauss")
         gm = float(x.mean()) if gauss else 0.0
-        shift = -gm if gauss else (1.0 if kind == "hpf" else 0.0)          # the drivers' preprocessing
+        shift = -gm if gauss else (1.0 if kind in ("hpf", "poisson_ext") else 0.0)      # the drivers' preprocessing
         U, I = int(u.max()) + 1, int(i.max()) + 1
         meta = {"kind": kind, "config": _config(kind, rng), "global_mean": gm, "validate": bool(rng.random() < 0.8)}
         metas.append((meta, shape))

@@ -423,6 +423,24 @@ def sweep_medium(n_trials, seed):
     return bad, worst
 
 
+def sweep_threads(n_threads, trials_per_thread, seed):
+    """The same parity trials from several host threads at once, every thread on contexts of its own (what the
+    tuner's concurrent trials do): distinct contexts are independent -- separate streams, buffers, error strings.
+    Returns the number of failures over all threads."""
+    import threading
+    results = [None] * n_threads
+
+    def work(k):
+        results[k] = sweep(trials_per_thread, seed + k, quiet=True)[0]
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    return sum(r if r is not None else trials_per_thread for r in results)
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     failures, worst_by_kind = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -69,3 +69,9 @@ def test_medium_problems_with_64_to_256_rating_tasks_match_the_oracle(capsys):
     failures, worst = fuzz_parity.sweep_medium(4, seed=8)
     assert failures == 0, capsys.readouterr().out
     assert worst <= 1e-11
+
+
+def test_random_problems_from_concurrent_host_threads(capsys):
+    """Six host threads run parity trials at once, each on its own contexts."""
+    import fuzz_parity
+    assert fuzz_parity.sweep_threads(6, 25, seed=50) == 0, capsys.readouterr().out

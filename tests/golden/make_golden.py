@@ -362,8 +362,42 @@ def gen_hpf_torch():
     }
 
 
+def gen_config5():
+    """BASELINE config #5: the reference's Poisson MF, K = 64, a0 = 0.1, b0 = 0.5
+    (best_hyperparams.txt:4), 150 iterations, on the recipe-shaped stand-in (tests/helpers.py:recipe_standin,
+    train + validation rows as the full-training driver uses them).  About a minute of the reference's loop.
+    Stored: test-set predictions and RMSE, 300 sampled users' factor rows and top-11 item lists with scores,
+    checksums of both factor matrices."""
+    here = os.path.dirname(OUT)
+    sys.path.append(here)                                                        # tests/helpers.py
+    sys.path.append(os.path.join(os.path.dirname(here), "prob-matrix-factorization_amd"))   # pmf_hip.synth only: appended, so `src` stays the reference's
+    from helpers import recipe_standin
+    train, val, test = recipe_standin()
+    tr = pd.concat([train, val])
+    cfg = dict(n_factors=64, a0=0.1, b0=0.5, max_iter=150, tol=None, random_state=42, verbose=False)
+    m, _ = quiet(lambda: make("poisson", cfg).fit(tr))
+    pred = m.predict(test["u"].to_numpy(), test["i"].to_numpy())
+    users = np.random.default_rng(1).choice(m.n_users, 300, replace=False)
+    early, _ = quiet(lambda: make("poisson", dict(cfg, max_iter=20)).fit(tr))      # a cheaper pin for the CPU oracle test
+    scores = m.E_theta[users] @ m.E_beta.T
+    top = np.argsort(-scores, axis=1, kind="stable")[:, :11]
+    return {"cfg": np.array(json.dumps({k: v for k, v in cfg.items() if k != "verbose"})),
+            "n_train_rows": np.int64(len(tr)), "n_test_rows": np.int64(len(test)),
+            "test_pred": pred, "test_rmse": np.float64(ref_metrics.rmse(test["rating"].to_numpy(dtype=float), pred)),
+            "users": users, "E_theta_rows": m.E_theta[users], "top11": top.astype(np.int32),
+            "top11_scores": np.take_along_axis(scores, top, axis=1),
+            "E_theta_sum": np.float64(m.E_theta.sum()), "E_beta_sum": np.float64(m.E_beta.sum()),
+            "test_pred_it20": early.predict(test["u"].to_numpy(), test["i"].to_numpy()),
+            "E_theta_rows_it20": early.E_theta[users]}
+
+
 def main():
     only = sys.argv[1:]
+    if "config5" in only:
+        path = os.path.join(OUT, "config5_poisson.npz")
+        np.savez_compressed(path, **gen_config5())
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+        return
     if not only or "headline" in only:
         for kind, K in HEADLINE:
             path = os.path.join(OUT, f"hk_{kind}_k{K}.npz")

@@ -70,3 +70,15 @@ def sgd_stats(ctx, device):
 def gauss_stats(ctx, device):
     return (DeviceStats(ctx.n_items * (ctx.cov_stride + ctx.kpad), ctx.np_dtype, device),
             DeviceStats(ctx.n_items * 2, ctx.np_dtype, device))
+
+
+def recipe_standin(n_users=11_780, n_items=13_000, nnz=320_000):
+    """The synthetic stand-in for the processed Food.com data (BASELINE config #5 shape; the real CSVs cannot be
+    fetched offline): (train, validation, test) frames.  Deterministic -- tests/golden/config5_poisson.npz holds
+    what the REFERENCE computes on exactly these frames."""
+    from pmf_hip.synth import synth_ratings
+    u, i, r = synth_ratings(n_users, n_items, nnz, seed=5)
+    u[0], i[0] = n_users - 1, n_items - 1
+    part = np.random.default_rng(0).choice(3, size=len(u), p=[0.85, 0.075, 0.075])
+    part[0] = 0
+    return tuple(pd.DataFrame({"u": u[part == k], "i": i[part == k], "rating": r[part == k]}) for k in range(3))

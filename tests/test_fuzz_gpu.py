@@ -66,7 +66,7 @@ def test_random_rating_lists_device_index_equals_host_index(capsys):
 def test_medium_problems_with_64_to_256_rating_tasks_match_the_oracle(capsys):
     """2.2M-9M ratings: the task lengths between the small tests' 32 and the full-size tests' 512."""
     import fuzz_parity
-    failures, worst = fuzz_parity.sweep_medium(4, seed=8)
+    failures, worst = fuzz_parity.sweep_medium(3, seed=8)
     assert failures == 0, capsys.readouterr().out
     assert worst <= 1e-11
 

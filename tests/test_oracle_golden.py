@@ -172,3 +172,21 @@ def test_headline_k_states_and_trajectory(path, vectorised):
     np.testing.assert_allclose(hist["val_rmse"], d["traj_val_rmse"], rtol=1e-10)
     if kind != "gauss":
         np.testing.assert_allclose(hist["val_macro_mae"], d["traj_val_macro_mae"], rtol=1e-10)
+
+
+def test_oracle_reproduces_the_reference_at_baseline_config5(golden_dir):
+    """config5_poisson.npz: the reference's Poisson MF K = 64 on the recipe-shaped stand-in (11,780 x 13,000, 295k
+    train + validation rows).  The oracle (vectorised form) on the same frames, at the fixture's 20-iteration
+    state (the 150-iteration state is what the GPU test is held to; here it would take minutes of CPU)."""
+    import json
+    import pandas as pd
+    from helpers import recipe_standin
+    ref = np.load(os.path.join(golden_dir, "config5_poisson.npz"))
+    train, val, test = recipe_standin()
+    tr = pd.concat([train, val])
+    assert (len(tr), len(test)) == (int(ref["n_train_rows"]), int(ref["n_test_rows"]))
+    st, _ = orc.fit("poisson", tr["u"].to_numpy(), tr["i"].to_numpy(), tr["rating"].to_numpy(dtype=float),
+                    dict(json.loads(str(ref["cfg"])), max_iter=20), vectorised=True)
+    pred = orc.predict_dot(st["E_theta"], st["E_beta"], test["u"].to_numpy(), test["i"].to_numpy())
+    np.testing.assert_allclose(pred, ref["test_pred_it20"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(st["E_theta"][ref["users"]], ref["E_theta_rows_it20"], rtol=1e-9, atol=1e-13)

@@ -34,12 +34,42 @@ KINDS = {"hpf": (HPF_CAVI, HPF_CAVI_Config, ["gamma_a_theta", "gamma_b_theta", "
          "gauss": (Gauss, GaussCfg, ["m_theta", "m_beta", "V_theta", "V_beta"])}
 
 
+def torch_case(d, t, meta, out):
+    """The PyTorch HPF model: parameters drawn under torch.manual_seed, loss and its four gradient tables on a batch,
+    a few Adam steps (the external loop of train_hpf_pytorch_full.py:96-108 without the shuffle), predict."""
+    import torch
+    from src.models.hpf_pytorch import HPF_PyTorch, HPF_PyTorch_Config
+    torch.manual_seed(meta["seed"])
+    m = HPF_PyTorch(meta["n_users"], meta["n_items"], d[f"t{t}_user_counts"], d[f"t{t}_item_counts"],
+                    HPF_PyTorch_Config(**meta["config"]))
+    bu, bi = torch.from_numpy(d[f"t{t}_bu"]), torch.from_numpy(d[f"t{t}_bi"])
+    br = torch.from_numpy(d[f"t{t}_br"])
+    for name in ("theta_uncons", "beta_uncons", "xi_uncons", "eta_uncons"):
+        out[f"t{t}_{name}"] = getattr(m, name).detach().numpy().copy()
+    loss = m.loss(bu, bi, br)
+    loss.backward()
+    out[f"t{t}_loss"] = np.float64(loss.item())
+    for name in ("theta_uncons", "beta_uncons", "xi_uncons", "eta_uncons"):
+        out[f"t{t}_grad_{name}"] = getattr(m, name).grad.numpy().copy()
+    opt = torch.optim.Adam(m.parameters(), lr=meta["config"]["lr"])
+    for _ in range(meta["steps"]):
+        opt.zero_grad()
+        m.loss(bu, bi, br).backward()
+        opt.step()
+    m.eval()
+    out[f"t{t}_predict"] = np.asarray(m.predict(d[f"t{t}_qu"], d[f"t{t}_qi"]), dtype=np.float64)
+    out[f"t{t}_theta_after"] = m.theta.detach().numpy().copy()
+
+
 def main(src, dst):
     d = np.load(src, allow_pickle=False)
     n = int(d["n_trials"])
     out = {}
     for t in range(n):
         meta = json.loads(str(d[f"t{t}_cfg"]))
+        if meta["kind"] == "hpf_torch":
+            torch_case(d, t, meta, out)
+            continue
         cls, cfg_cls, keys = KINDS[meta["kind"]]
         train = pd.DataFrame({"u": d[f"t{t}_u"], "i": d[f"t{t}_i"], "rating": d[f"t{t}_x"]})
         val = pd.DataFrame({"u": d[f"t{t}_vu"], "i": d[f"t{t}_vi"], "rating": d[f"t{t}_vx"]}) if meta["validate"] else None

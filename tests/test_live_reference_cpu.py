@@ -126,3 +126,60 @@ def test_random_problems_host_logic_equals_the_live_reference(tmp_path, monkeypa
         assert ebuf.getvalue() == str(ref[f"t{t}_eval_stdout"]), tag
     # the sweep really went through the interesting branches
     assert seen["kinds"] == set(KEYS) and seen["validated"] >= 80 and seen["stopped_early"] >= 10, seen
+
+
+def test_random_hpf_pytorch_cases_equal_the_live_reference(tmp_path):
+    """The PyTorch HPF model (row a13) against the reference's, run live: identical initial parameters under the
+    same torch seed, loss value and all four gradient tables on a random batch, then a few Adam steps and
+    `predict` (ids outside the tables included)."""
+    import torch
+    from src.models.hpf_pytorch import HPF_PyTorch, HPF_PyTorch_Config
+    rng = np.random.default_rng(7)
+    n_trials = 25
+    inputs, metas = {"n_trials": np.asarray(n_trials)}, []
+    for t in range(n_trials):
+        U, I, K = int(rng.integers(1, 60)), int(rng.integers(1, 40)), int(rng.choice([1, 3, 8, 20]))
+        n = int(rng.integers(1, 300))
+        u, i = rng.integers(0, U, n), rng.integers(0, I, n)
+        config = dict(n_factors=K, a=float(rng.choice([0.3, 1.0])), a_prime=float(rng.choice([1.0, 3.0])), b_prime=1.0,
+                      c=float(rng.choice([0.3, 1.0])), c_prime=1.0, d_prime=float(rng.choice([0.7, 1.0])), lr=0.01, verbose=False)
+        meta = {"kind": "hpf_torch", "n_users": U, "n_items": I, "config": config, "seed": int(rng.integers(0, 1000)),
+                "steps": int(rng.integers(1, 5))}
+        metas.append(meta)
+        inputs.update({f"t{t}_user_counts": np.bincount(u, minlength=U).astype(np.float64),
+                       f"t{t}_item_counts": np.bincount(i, minlength=I).astype(np.float64),
+                       f"t{t}_bu": u, f"t{t}_bi": i, f"t{t}_br": (rng.integers(0, 6, n) + 1).astype(np.float32),
+                       f"t{t}_qu": rng.integers(0, U, 15), f"t{t}_qi": rng.integers(0, I, 15),
+                       f"t{t}_cfg": np.asarray(json.dumps(meta))})
+    src, dst = str(tmp_path / "torch_problems.npz"), str(tmp_path / "torch_reference_out.npz")
+    np.savez(src, **inputs)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference.py"), src, dst], env=env,
+                          capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert done.returncode == 0, done.stderr[-2000:]
+    ref = np.load(dst, allow_pickle=False)
+    names = ("theta_uncons", "beta_uncons", "xi_uncons", "eta_uncons")
+    for t, meta in enumerate(metas):
+        tag = f"trial {t}: {meta}"
+        torch.manual_seed(meta["seed"])
+        m = HPF_PyTorch(meta["n_users"], meta["n_items"], inputs[f"t{t}_user_counts"], inputs[f"t{t}_item_counts"],
+                        HPF_PyTorch_Config(**meta["config"]))
+        for name in names:          # the same draws, in the same order
+            assert np.array_equal(getattr(m, name).detach().numpy(), ref[f"t{t}_{name}"]), f"{tag}: {name}"
+        bu, bi = torch.from_numpy(inputs[f"t{t}_bu"]), torch.from_numpy(inputs[f"t{t}_bi"])
+        br = torch.from_numpy(inputs[f"t{t}_br"])
+        loss = m.loss(bu, bi, br)
+        loss.backward()
+        assert loss.item() == pytest.approx(float(ref[f"t{t}_loss"]), rel=2e-6, abs=1e-5), tag
+        for name in names:
+            np.testing.assert_allclose(getattr(m, name).grad.numpy(), ref[f"t{t}_grad_{name}"], rtol=1e-4, atol=2e-5,
+                                       err_msg=f"{tag}: grad {name}")
+        opt = torch.optim.Adam(m.parameters(), lr=meta["config"]["lr"])
+        for _ in range(meta["steps"]):
+            opt.zero_grad()
+            m.loss(bu, bi, br).backward()
+            opt.step()
+        m.eval()
+        np.testing.assert_allclose(m.predict(inputs[f"t{t}_qu"], inputs[f"t{t}_qi"]), ref[f"t{t}_predict"], rtol=1e-4,
+                                   atol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(m.theta.detach().numpy(), ref[f"t{t}_theta_after"], rtol=1e-4, atol=1e-6, err_msg=tag)

@@ -70,6 +70,15 @@ def main(src, dst):
         if meta["kind"] == "hpf_torch":
             torch_case(d, t, meta, out)
             continue
+        if meta["kind"] == "metrics":
+            from src.evaluation import metrics as M
+            y, p = d[f"t{t}_y"], d[f"t{t}_p"]
+            frame = pd.DataFrame({"u": d[f"t{t}_u"], "i": d[f"t{t}_i"], "rating": d[f"t{t}_x"]})
+            th, be = d[f"t{t}_theta"], d[f"t{t}_beta"]
+            out[f"t{t}_values"] = np.asarray([M.rmse(y, p), M.mae(y, p), M.macro_mae(y, p),
+                                              M.GaussianLogPredictiveLikelihood(frame, th, be, meta["sigma"]),
+                                              M.PoissonLogPredictiveLikelihood(frame, np.abs(th), np.abs(be))], dtype=np.float64)
+            continue
         cls, cfg_cls, keys = KINDS[meta["kind"]]
         train = pd.DataFrame({"u": d[f"t{t}_u"], "i": d[f"t{t}_i"], "rating": d[f"t{t}_x"]})
         val = pd.DataFrame({"u": d[f"t{t}_vu"], "i": d[f"t{t}_vi"], "rating": d[f"t{t}_vx"]}) if meta["validate"] else None

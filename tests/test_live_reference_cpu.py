@@ -183,3 +183,34 @@ def test_random_hpf_pytorch_cases_equal_the_live_reference(tmp_path):
         np.testing.assert_allclose(m.predict(inputs[f"t{t}_qu"], inputs[f"t{t}_qi"]), ref[f"t{t}_predict"], rtol=1e-4,
                                    atol=1e-5, err_msg=tag)
         np.testing.assert_allclose(m.theta.detach().numpy(), ref[f"t{t}_theta_after"], rtol=1e-4, atol=1e-6, err_msg=tag)
+
+
+def test_random_metric_inputs_equal_the_live_reference(tmp_path):
+    """`src.evaluation.metrics` (rmse, mae, macro_mae and the two log predictive likelihoods) on random inputs."""
+    from src.evaluation import metrics as M
+    rng = np.random.default_rng(3)
+    n_trials = 30
+    inputs = {"n_trials": np.asarray(n_trials)}
+    for t in range(n_trials):
+        n, U, I, K = int(rng.integers(1, 200)), int(rng.integers(1, 20)), int(rng.integers(1, 15)), int(rng.integers(1, 6))
+        y = rng.integers(0, 6, n).astype(np.float64) if t % 2 else rng.normal(size=n).round(1)
+        meta = {"kind": "metrics", "sigma": float(rng.uniform(0.3, 2.0))}
+        inputs.update({f"t{t}_y": y, f"t{t}_p": y + rng.normal(size=n), f"t{t}_u": rng.integers(0, U, n),
+                       f"t{t}_i": rng.integers(0, I, n), f"t{t}_x": rng.integers(0, 6, n).astype(np.float64),
+                       f"t{t}_theta": rng.normal(size=(U, K)), f"t{t}_beta": rng.normal(size=(I, K)),
+                       f"t{t}_cfg": np.asarray(json.dumps(meta)), f"t{t}_sigma": np.asarray(meta["sigma"])})
+    src, dst = str(tmp_path / "metric_inputs.npz"), str(tmp_path / "metric_reference_out.npz")
+    np.savez(src, **inputs)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference.py"), src, dst], env=env,
+                          capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert done.returncode == 0, done.stderr[-2000:]
+    ref = np.load(dst, allow_pickle=False)
+    for t in range(n_trials):
+        y, p = inputs[f"t{t}_y"], inputs[f"t{t}_p"]
+        frame = pd.DataFrame({"u": inputs[f"t{t}_u"], "i": inputs[f"t{t}_i"], "rating": inputs[f"t{t}_x"]})
+        th, be = inputs[f"t{t}_theta"], inputs[f"t{t}_beta"]
+        got = [M.rmse(y, p), M.mae(y, p), M.macro_mae(y, p),
+               M.GaussianLogPredictiveLikelihood(frame, th, be, float(inputs[f"t{t}_sigma"])),
+               M.PoissonLogPredictiveLikelihood(frame, np.abs(th), np.abs(be))]
+        np.testing.assert_allclose(np.asarray(got, dtype=np.float64), ref[f"t{t}_values"], rtol=1e-12, err_msg=f"trial {t}")

@@ -5,10 +5,10 @@ from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfi
 
 
 def train_full_gaussian(dataset_mode="train"):
-    print(f"=== Training Full Gaussian MF (Bias) | Mode: {dataset_mode} ===")
+    print(f"=== Training Full Gaussian MF (CAVI) | Mode: {dataset_mode} ===")      # the driver's lines as the reference prints them
     df, test_df = ft.load_frames(dataset_mode)
     global_mean = df["rating"].mean()          # mean of whatever is trained on (:35-38)
-    print(f"Centering data (global_mean={global_mean:.4f})...")
+    print(f"Centering data (Global Mean = {global_mean:.4f})...")
     centred = df.copy()
     centred["rating"] -= global_mean
     print("Loading best hyperparameters...")

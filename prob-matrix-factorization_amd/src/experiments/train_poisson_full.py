@@ -5,7 +5,7 @@ from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
 
 
 def train_full_poisson(dataset_mode="train"):
-    print(f"=== Training Full Poisson MF | Mode: {dataset_mode} ===")
+    print(f"=== Training Full Poisson MF (CAVI) | Mode: {dataset_mode} ===")
     df, test_df = ft.load_frames(dataset_mode)     # raw ratings, no preprocessing
     print("Loading best hyperparameters...")
     loaded = load_best_hyperparams().get("PoissonMF", {})

@@ -214,3 +214,84 @@ def test_random_metric_inputs_equal_the_live_reference(tmp_path):
                M.GaussianLogPredictiveLikelihood(frame, th, be, float(inputs[f"t{t}_sigma"])),
                M.PoissonLogPredictiveLikelihood(frame, np.abs(th), np.abs(be))]
         np.testing.assert_allclose(np.asarray(got, dtype=np.float64), ref[f"t{t}_values"], rtol=1e-12, err_msg=f"trial {t}")
+
+
+DRIVER_HYPER = """BEST CONFIGURATIONS
+===================
+GaussianMF: {'n_factors': 6, 'sigma2': 0.3, 'eta_theta2': 0.5, 'eta_beta2': 0.5, 'eta_bias2': 1.0, 'max_iter': 4, 'tol': 0.001, 'random_state': 42, 'verbose': False}
+PoissonMF: {'n_factors': 5, 'a0': 0.1, 'b0': 0.5, 'max_iter': 5, 'tol': None, 'random_state': 42, 'verbose': False}
+HPF_CAVI: {'n_factors': 4, 'a': 0.3, 'a_prime': 5.0, 'b_prime': 5.0, 'c': 0.3, 'c_prime': 5.0, 'd_prime': 5.0, 'max_iter': 5, 'tol': None, 'random_state': 42, 'verbose': False}
+HPF_PyTorch: {'n_factors': 3, 'a': 1.0, 'a_prime': 1.0, 'b_prime': 1.0, 'c': 1.0, 'c_prime': 1.0, 'd_prime': 1.0, 'lr': 0.0005, 'batch_size': 64, 'epochs': 1, 'device': 'cpu', 'verbose': False}
+"""
+
+
+def _tree(root):
+    return sorted(os.path.relpath(os.path.join(d, f), root) for d, _, fs in os.walk(os.path.join(root, "data")) for f in fs
+                  if "processed" not in d)
+
+
+@pytest.mark.parametrize("mode", ["train", "train+val"])
+def test_driver_outputs_on_disk_equal_the_live_reference(mode, tmp_path, monkeypatch):
+    """The on-disk surface: the four full-training drivers of the reference and of this repo
+    on the same tiny processed data and the same best_hyperparams.txt, each in a directory of its own -- same file
+    tree, same `config.txt` text, same CSV headers / shapes / index columns, same values (CAVI models: rtol 1e-9;
+    the PyTorch model's shuffled training is not pinned by the reference, so only its files' form is compared)."""
+    import pmf_hip
+    from oracle_engine import OracleContext
+    rng = np.random.default_rng(11)
+    n = 900
+    u, i = rng.integers(0, 40, n), rng.integers(0, 25, n)
+    u[0], i[0] = 39, 24
+    r = rng.integers(0, 6, n).astype(float)
+    part = rng.choice(3, size=n, p=[0.8, 0.1, 0.1])
+    part[0] = 0
+    roots = {}
+    for who in ("reference", "ours"):
+        root = tmp_path / who
+        d = root / "data" / "processed"
+        d.mkdir(parents=True)
+        for k, name in enumerate(("train", "validation", "test")):
+            pd.DataFrame({"u": u[part == k], "i": i[part == k], "rating": r[part == k]}).to_csv(d / f"interactions_{name}.csv", index=False)
+        (root / "best_hyperparams.txt").write_text(DRIVER_HYPER)
+        roots[who] = str(root)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference_drivers.py"), mode], env=env,
+                          capture_output=True, text=True, timeout=900, cwd=roots["reference"])
+    assert done.returncode == 0, done.stderr[-2000:]
+
+    monkeypatch.setattr(pmf_hip, "Context", OracleContext)
+    monkeypatch.chdir(roots["ours"])
+    from src.experiments.train_gaussian_full import train_full_gaussian
+    from src.experiments.train_hpf_cavi_full import train_full_hpf_cavi
+    from src.experiments.train_hpf_pytorch_full import train_full_hpf_pytorch
+    from src.experiments.train_poisson_full import train_full_poisson
+    ours_out = {}
+    for name, fn in (("gaussian_mf", train_full_gaussian), ("poisson_mf", train_full_poisson), ("hpf_cavi", train_full_hpf_cavi),
+                     ("hpf_pytorch", train_full_hpf_pytorch)):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            fn(dataset_mode=mode)
+        ours_out[name] = buf.getvalue()
+
+    assert _tree(roots["ours"]) == _tree(roots["reference"])
+    for rel in _tree(roots["reference"]):
+        a, b = os.path.join(roots["ours"], rel), os.path.join(roots["reference"], rel)
+        if rel.endswith("config.txt"):
+            assert open(a).read() == open(b).read(), rel
+            continue
+        fa, fb = pd.read_csv(a), pd.read_csv(b)
+        assert list(fa.columns) == list(fb.columns) and fa.shape == fb.shape, rel
+        assert open(a).readline() == open(b).readline(), rel                     # the header line, byte for byte
+        if "hpf_pytorch" in rel:
+            keys = [c for c in fa.columns if c in ("u", "i", "y_true")]
+            assert fa[keys].equals(fb[keys]), rel
+            continue
+        np.testing.assert_allclose(fa.to_numpy(dtype=float), fb.to_numpy(dtype=float), rtol=1e-9, atol=1e-12, err_msg=rel)
+    # what the drivers print (timings differ; the PyTorch loop's loss values are not pinned)
+    for name in ("gaussian_mf", "poisson_mf", "hpf_cavi"):
+        theirs = open(os.path.join(roots["reference"], f"stdout_{name}.txt")).read().splitlines()
+        mine = ours_out[name].splitlines()
+        strip = lambda lines: [ln for ln in lines if "seconds" not in ln and "Time" not in ln and "time" not in ln]   # noqa: E731
+        import difflib
+        delta = "\n".join(difflib.unified_diff(strip(theirs), strip(mine), "reference", "ours", lineterm="", n=0))
+        assert strip(mine) == strip(theirs), f"{name}\n{delta}"

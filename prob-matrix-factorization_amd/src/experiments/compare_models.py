@@ -48,8 +48,9 @@ def _row(label, scores, seconds, config):
             "Val MacroMAE": vm, "Test MacroMAE": sm, "Time (s)": seconds, "Config": str(asdict(config))}
 
 
-def _timed(tag, fit):
-    print(f"     [{tag}] Starting training...", flush=True)
+def _timed(tag, fit, note=""):
+    # `note`: the reference's lines carry fixed texts here, whatever the configuration says (:86, :301)
+    print(f"     [{tag}] Starting training{note}...", flush=True)
     t0 = time.time()
     fit()
     dt = time.time() - t0
@@ -74,7 +75,7 @@ def run_gaussian_mf(train_df, val_df, test_df, config_dict=None, verbose=False):
         config = GaussianMFCAVIConfig(n_factors=20, sigma2=0.5, eta_theta2=0.1, eta_beta2=0.01, eta_bias2=0.01,
                                       max_iter=100, tol=1e-8, random_state=42, verbose=verbose)
     model = GaussianMFCAVI(config)
-    dt = _timed("GaussianMF", lambda: model.fit(centred[0], val_df=centred[1], global_mean=global_mean))
+    dt = _timed("GaussianMF", lambda: model.fit(centred[0], val_df=centred[1], global_mean=global_mean), " (max_iter=100)")
     print("     [GaussianMF] Evaluating...", flush=True)
     scores = []
     for raw, cen in zip((train_df, val_df, test_df), centred):
@@ -163,7 +164,7 @@ def run_hpf_pytorch(train_df, val_df, test_df, config_dict=None, verbose=False):
     i = torch.from_numpy(shifted[0]["i"].to_numpy()).long().to(device)
     r = torch.from_numpy(shifted[0]["rating"].to_numpy(dtype=np.float32)).to(device)
     # the comparison script uses a fixed batch of 4096, not the config's (:299)
-    dt = _timed("HPF_PyTorch", lambda: adam_epochs(model, u, i, r, config.lr, 4096, config.epochs, verbose, 5))
+    dt = _timed("HPF_PyTorch", lambda: adam_epochs(model, u, i, r, config.lr, 4096, config.epochs, verbose, 5), " (epochs=50)")
     model.eval()
     return _row("HPF (PyTorch)", _unshifted_scores(model.predict, shifted), dt, config)
 
@@ -199,6 +200,7 @@ def main():
             traceback.print_exc()
     results_df = pd.DataFrame(results)
     print("\n=== FINAL RESULTS ===", flush=True)
+    print("\n=== FINAL RESULTS ===", flush=True)          # (twice, as the reference does: compare_models.py:482-483)
     if len(results_df):
         print(results_df[COLUMNS])
         save_results(results_df)

@@ -253,6 +253,13 @@ def test_driver_outputs_on_disk_equal_the_live_reference(mode, tmp_path, monkeyp
         for k, name in enumerate(("train", "validation", "test")):
             pd.DataFrame({"u": u[part == k], "i": i[part == k], "rating": r[part == k]}).to_csv(d / f"interactions_{name}.csv", index=False)
         (root / "best_hyperparams.txt").write_text(DRIVER_HYPER)
+        if mode == "train+val":
+            # with the optional mapping files present (src/utils/mapping.py) item_embeddings.csv gets a leading
+            # recipe_id column; one model index has no recipe (-> -1 and a warning)
+            (root / "data" / "raw").mkdir()
+            raw_ids = np.random.default_rng(1).permutation(200)[:25]
+            pd.DataFrame({"i_new": np.arange(25), "i": raw_ids}).to_csv(d / "dict_i.csv", index=False)
+            pd.DataFrame({"id": 5000 + raw_ids[:-1], "i": raw_ids[:-1], "other": 0}).to_csv(root / "data" / "raw" / "PP_recipes.csv", index=False)
         roots[who] = str(root)
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference_drivers.py"), mode], env=env,
@@ -281,6 +288,8 @@ def test_driver_outputs_on_disk_equal_the_live_reference(mode, tmp_path, monkeyp
             continue
         fa, fb = pd.read_csv(a), pd.read_csv(b)
         assert list(fa.columns) == list(fb.columns) and fa.shape == fb.shape, rel
+        if rel.endswith("item_embeddings.csv"):
+            assert ("recipe_id" in fa.columns) == (mode == "train+val"), rel
         assert open(a).readline() == open(b).readline(), rel                     # the header line, byte for byte
         if "hpf_pytorch" in rel:
             keys = [c for c in fa.columns if c in ("u", "i", "y_true")]

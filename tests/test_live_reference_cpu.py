@@ -375,3 +375,46 @@ def test_named_drivers_print_what_the_reference_prints(tmp_path, monkeypatch):
     # the metadata file compare_models leaves behind (compare_models.py:428-433)
     assert open(os.path.join(roots["ours"], "model_comparison_params.txt")).read() == \
         open(os.path.join(roots["reference"], "model_comparison_params.txt")).read()
+
+
+def test_tuner_writes_the_file_the_reference_writes(tmp_path, monkeypatch):
+    """`tune_all_models.main()` on both sides, one trial per model: the reference samples its grids with an unseeded
+    `random.choice`, so the VALUES differ by construction -- the file's form must not: the two header lines, one
+    line per model in the same order, and per model the same keys in the same order with values of the same types
+    (the drivers build `Config(**dict)` from these lines)."""
+    import ast
+    import pmf_hip
+    from oracle_engine import OracleContext
+    rng = np.random.default_rng(13)
+    n = 700
+    u, i = rng.integers(0, 30, n), rng.integers(0, 20, n)
+    u[0], i[0] = 29, 19
+    r = rng.integers(0, 6, n).astype(float)
+    part = rng.choice(3, size=n, p=[0.8, 0.1, 0.1])
+    part[0] = 0
+    roots = {}
+    for who in ("reference", "ours"):
+        d = tmp_path / who / "data" / "processed"
+        d.mkdir(parents=True)
+        for k, name in enumerate(("train", "validation", "test")):
+            pd.DataFrame({"u": u[part == k], "i": i[part == k], "rating": r[part == k]}).to_csv(d / f"interactions_{name}.csv", index=False)
+        roots[who] = str(tmp_path / who)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference_tuner.py")], env=env,
+                          capture_output=True, text=True, timeout=900, cwd=roots["reference"])
+    assert done.returncode == 0, done.stderr[-2000:]
+    monkeypatch.setattr(pmf_hip, "Context", OracleContext)
+    monkeypatch.chdir(roots["ours"])
+    monkeypatch.setattr(sys, "argv", ["tune_all_models", "--n_trials", "1"])
+    from src.experiments import tune_all_models
+    with contextlib.redirect_stdout(io.StringIO()):
+        tune_all_models.main()
+    theirs = open(os.path.join(roots["reference"], "best_hyperparams.txt")).read().splitlines()
+    mine = open(os.path.join(roots["ours"], "best_hyperparams.txt")).read().splitlines()
+    assert mine[:2] == theirs[:2] == ["BEST CONFIGURATIONS", "==================="]
+    assert len(mine) == len(theirs) == 6
+    for a, b in zip(mine[2:], theirs[2:]):
+        (name_a, text_a), (name_b, text_b) = a.split(":", 1), b.split(":", 1)
+        da, db = ast.literal_eval(text_a.strip()), ast.literal_eval(text_b.strip())
+        assert name_a == name_b and list(da) == list(db), (a, b)
+        assert [type(v) for v in da.values()] == [type(v) for v in db.values()], (a, b)

@@ -418,3 +418,37 @@ def test_tuner_writes_the_file_the_reference_writes(tmp_path, monkeypatch):
         da, db = ast.literal_eval(text_a.strip()), ast.literal_eval(text_b.strip())
         assert name_a == name_b and list(da) == list(db), (a, b)
         assert [type(v) for v in da.values()] == [type(v) for v in db.values()], (a, b)
+
+
+def test_torch_grid_search_prints_the_reference_protocol(tmp_path, monkeypatch):
+    """`tune_hpf_pytorch.run_tuning()` on both sides (the full 16-combination grid, 10 epochs each, tiny data): the
+    same protocol lines in the same order; the RMSE values are not pinned (unseeded shuffles / initialisation)."""
+    rng = np.random.default_rng(14)
+    n = 400
+    u, i = rng.integers(0, 25, n), rng.integers(0, 15, n)
+    r = rng.integers(0, 6, n).astype(float)
+    part = rng.choice(3, size=n, p=[0.8, 0.1, 0.1])
+    roots = {}
+    for who in ("reference", "ours"):
+        d = tmp_path / who / "data" / "processed"
+        d.mkdir(parents=True)
+        for k, name in enumerate(("train", "validation", "test")):
+            pd.DataFrame({"u": u[part == k], "i": i[part == k], "rating": r[part == k]}).to_csv(d / f"interactions_{name}.csv", index=False)
+        roots[who] = str(tmp_path / who)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "live_reference_tune_torch.py")], env=env,
+                          capture_output=True, text=True, timeout=900, cwd=roots["reference"])
+    assert done.returncode == 0, done.stderr[-2000:]
+    monkeypatch.chdir(roots["ours"])
+    from src.experiments import tune_hpf_pytorch
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        tune_hpf_pytorch.run_tuning()
+
+    def protocol(text):      # the lines that do not carry a measured value
+        return [ln for ln in text.splitlines() if ln.strip() and not ln.startswith(("Result RMSE", "*** New Best", "Best Validation",
+                                                                                     "Best Configuration"))]
+    theirs = protocol(open(os.path.join(roots["reference"], "stdout_tune_torch.txt")).read())
+    assert protocol(buf.getvalue()) == theirs and len(theirs) == 2 + 16
+    for text in (buf.getvalue(), open(os.path.join(roots["reference"], "stdout_tune_torch.txt")).read()):
+        assert text.count("Result RMSE: ") == 16 and "Best Configuration: {" in text and "Best Validation RMSE: " in text

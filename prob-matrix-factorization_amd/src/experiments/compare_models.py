@@ -164,7 +164,8 @@ def run_hpf_pytorch(train_df, val_df, test_df, config_dict=None, verbose=False):
     i = torch.from_numpy(shifted[0]["i"].to_numpy()).long().to(device)
     r = torch.from_numpy(shifted[0]["rating"].to_numpy(dtype=np.float32)).to(device)
     # the comparison script uses a fixed batch of 4096, not the config's (:299)
-    dt = _timed("HPF_PyTorch", lambda: adam_epochs(model, u, i, r, config.lr, 4096, config.epochs, verbose, 5), " (epochs=50)")
+    dt = _timed("HPF_PyTorch", lambda: adam_epochs(model, u, i, r, config.lr, 4096, config.epochs, verbose, 5,
+                                                   prefix="     [HPF_PyTorch] "), " (epochs=50)")
     model.eval()
     return _row("HPF (PyTorch)", _unshifted_scores(model.predict, shifted), dt, config)
 

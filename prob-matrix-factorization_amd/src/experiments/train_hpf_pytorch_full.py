@@ -55,7 +55,7 @@ def _graphed_step(model, optimizer, batch_size, u, i, r):
     return static_idx, static_loss, graph
 
 
-def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=1, graph=None, on_epoch=None):
+def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=1, graph=None, on_epoch=None, prefix=""):
     """The reference's external training loop (train_hpf_pytorch_full.py:96-108):
     Adam over all parameters, shuffled minibatches, one pass per epoch.
 
@@ -91,7 +91,7 @@ def adam_epochs(model, u, i, r, lr, batch_size, epochs, verbose=True, log_every=
             optimizer.step()
             total += loss.detach()
         if verbose and (epoch % log_every == 0 or epoch == epochs - 1):
-            print(f"Epoch {epoch + 1}/{epochs} Loss: {total.item():.4f}")
+            print(f"{prefix}Epoch {epoch + 1}/{epochs} Loss: {total.item():.4f}", flush=bool(prefix))   # (compare_models.py:316 tags and flushes its lines)
         if on_epoch is not None:
             on_epoch(epoch)
     model.training_info_ = {"graph_replays": replays, "steps": epochs * ((n + batch_size - 1) // batch_size)}
@@ -123,7 +123,7 @@ def train_full_hpf_pytorch(dataset_mode="train"):
     u = torch.from_numpy(shifted["u"].to_numpy()).long().to(device)
     i = torch.from_numpy(shifted["i"].to_numpy()).long().to(device)
     r = torch.from_numpy(shifted["rating"].to_numpy(dtype=np.float32)).to(device)
-    ft.timed_fit(lambda: adam_epochs(model, u, i, r, config.lr, batch_size, config.epochs, config.verbose))
+    ft.timed_fit(lambda: adam_epochs(model, u, i, r, config.lr, batch_size, config.epochs, verbose=True))   # every epoch, whatever config.verbose says (:108)
     model.eval()
     ft.write_embeddings("hpf_pytorch", model.theta.detach().cpu().numpy(), model.beta.detach().cpu().numpy(), config)
     print("Generating predictions on Test Set...")

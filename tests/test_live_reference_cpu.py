@@ -411,8 +411,19 @@ def test_tuner_writes_the_file_the_reference_writes(tmp_path, monkeypatch):
     monkeypatch.chdir(roots["ours"])
     monkeypatch.setattr(sys, "argv", ["tune_all_models", "--n_trials", "1"])
     from src.experiments import tune_all_models
-    with contextlib.redirect_stdout(io.StringIO()):
+    captured = io.StringIO()
+    with contextlib.redirect_stdout(captured):
         tune_all_models.main()
+    import difflib
+    import re
+
+    def shape_of(text):      # every number masked: the sampled configurations and their scores differ by construction
+        return [re.sub(r"[-+]?\d+(?:\.\d+)?(?:e[-+]?\d+)?", "#", ln.rstrip()) for ln in text.splitlines()
+                if not any(w in ln for w in ("Time", "time", "seconds"))]
+    said_theirs = shape_of(open(os.path.join(roots["reference"], "stdout_tune.txt")).read())
+    said_mine = shape_of(captured.getvalue())
+    delta = "\n".join(difflib.unified_diff(said_theirs, said_mine, "reference", "ours", lineterm="", n=0))
+    assert said_mine == said_theirs, delta
     theirs = open(os.path.join(roots["reference"], "best_hyperparams.txt")).read().splitlines()
     mine = open(os.path.join(roots["ours"], "best_hyperparams.txt")).read().splitlines()
     assert mine[:2] == theirs[:2] == ["BEST CONFIGURATIONS", "==================="]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMF_ABI_VERSION 2
+#define PMF_ABI_VERSION 3
 
 /* error codes */
 #define PMF_OK 0
@@ -153,6 +153,14 @@ int pmf_ctx_set_ratings(pmf_ctx *ctx, int64_t nnz, const int32_t *user_ids,
  * C-contiguous.  Setting an array allocates it. */
 int pmf_set_array(pmf_ctx *ctx, int side, int array, const double *host);
 int pmf_get_array(pmf_ctx *ctx, int side, int array, double *host);
+/* Row subsets of the same arrays: `rows[n]` are row ids of `side` (any order, repeats allowed when
+ * reading; when writing, a repeated row ends with one of its values); `host` holds n rows in the
+ * layout above (n x K, n, or n x K x K doubles).  What the reference's row indexing does
+ * (`V_beta[j_idx]`, `m_beta[j_idx]`, `V_theta[i] = ...`: gaussian_mf_cavi_bias.py:146-162) without
+ * moving the whole stack: V_theta at 1M x 64 x 64 is 32.8 GB as host float64, 164 GB at the K = 128
+ * shard of config C4.  A row id outside [0, rows) is PMF_ERANGE and nothing is copied. */
+int pmf_get_array_rows(pmf_ctx *ctx, int side, int array, int64_t n, const int64_t *rows, double *host);
+int pmf_set_array_rows(pmf_ctx *ctx, int side, int array, int64_t n, const int64_t *rows, const double *host);
 /* COV shortcut for `_initialize_variational_params`
  * (gaussian_mf_cavi_bias.py:64-67): every row's covariance = scale * I. */
 int pmf_set_cov_identity(pmf_ctx *ctx, int side, double scale);

@@ -831,6 +831,101 @@ extern "C" int pmf_get_array(pmf_ctx *ctx, int side, int array, double *host) {
     return PMF_OK;
 }
 
+// ---------------------------------------------------------------------------
+// row-subset exchange: the reference's callers index rows of the state (V_theta[i], m_beta[j_idx]:
+// gaussian_mf_cavi_bias.py:146-162); at 1M+ rows a K x K covariance stack is tens of GB as host float64,
+// so a caller that wants a few rows gets a few rows.  Rows are gathered / scattered on the device in
+// units of 16 bytes (per-row scalars: one element), 64-bit offsets throughout.
+// ---------------------------------------------------------------------------
+template <typename U, bool SCATTER>
+__global__ void rows_copy_kernel(U *table, U *staged, const int64_t *rows, int64_t n, int64_t units_per_row) {
+    const int64_t total = n * units_per_row;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / units_per_row, w = t - r * units_per_row;
+        U *at = table + rows[r] * units_per_row + w;
+        if (SCATTER) *at = staged[t];
+        else staged[t] = *at;
+    }
+}
+
+template <bool SCATTER>
+static void launch_rows_copy(pmf_ctx *ctx, void *table, void *staged, const int64_t *d_rows, int64_t n, int64_t row_bytes) {
+    const bool wide = row_bytes % 16 == 0;
+    const int64_t unit = wide ? 16 : (int64_t)ctx->elem, upr = row_bytes / unit;
+    const unsigned grid = (unsigned)std::min<int64_t>((n * upr + 255) / 256, 65536);
+    if (wide)
+        hipLaunchKernelGGL((rows_copy_kernel<uint4, SCATTER>), dim3(grid), dim3(256), 0, ctx->stream, (uint4 *)table,
+                           (uint4 *)staged, d_rows, n, upr);
+    else if (unit == 8)
+        hipLaunchKernelGGL((rows_copy_kernel<uint2, SCATTER>), dim3(grid), dim3(256), 0, ctx->stream, (uint2 *)table,
+                           (uint2 *)staged, d_rows, n, upr);
+    else
+        hipLaunchKernelGGL((rows_copy_kernel<uint32_t, SCATTER>), dim3(grid), dim3(256), 0, ctx->stream, (uint32_t *)table,
+                           (uint32_t *)staged, d_rows, n, upr);
+}
+
+// shared body of pmf_get_array_rows (host_out) / pmf_set_array_rows (host_in)
+static int array_rows_impl(pmf_ctx *ctx, int side, int array, int64_t n, const int64_t *rows, const double *host_in,
+                           double *host_out, const char *fn) {
+    PMF_REQUIRE(ctx != nullptr, PMF_EINVAL, "%s: null context", fn);
+    PMF_REQUIRE(side == PMF_SIDE_USER || side == PMF_SIDE_ITEM, PMF_EINVAL, "%s: bad side %d", fn, side);
+    PMF_REQUIRE(array >= 0 && array < PMF_ARR_COUNT, PMF_EINVAL, "%s: bad array id %d", fn, array);
+    PMF_REQUIRE(n >= 0, PMF_EINVAL, "%s: negative row count", fn);
+    if (n == 0) return PMF_OK;
+    PMF_REQUIRE(rows && (host_in || host_out), PMF_EINVAL, "%s: null argument", fn);
+    for (int64_t k = 0; k < n; ++k)
+        PMF_REQUIRE(rows[k] >= 0 && rows[k] < ctx->rows[side], PMF_ERANGE, "%s: row %lld at position %lld outside [0, %lld)",
+                    fn, (long long)rows[k], (long long)k, (long long)ctx->rows[side]);
+    PMF_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = host_in ? pmf_alloc_array(ctx, side, array) : pmf_require_array(ctx, side, array, fn);
+    if (rc) return rc;
+    int width, stride;
+    pmf_array_shape(ctx, array, &width, &stride);
+    const int64_t row_bytes = (int64_t)stride * (int64_t)ctx->elem;
+    const int64_t step = std::min(n, std::max<int64_t>(1, kStageBytes / row_bytes));
+    // device staging: [step rows of the array's layout][step row ids]; the host side of it is the pinned buffer
+    const size_t data_bytes = (size_t)((step * row_bytes + 15) / 16 * 16);
+    if ((rc = pmf_ensure_scratch(ctx, data_bytes + (size_t)step * sizeof(int64_t)))) return rc;
+    if ((rc = pmf_ensure_pinned(ctx, std::max(data_bytes, (size_t)step * sizeof(int64_t))))) return rc;
+    char *d_data = (char *)ctx->d_scratch;
+    int64_t *d_rows = (int64_t *)(d_data + data_bytes);
+    for (int64_t r0 = 0; r0 < n; r0 += step) {
+        const int64_t nr = std::min(step, n - r0);
+        memcpy(ctx->h_pinned, rows + r0, (size_t)nr * sizeof(int64_t));
+        PMF_HIP_CHECK(hipMemcpyAsync(d_rows, ctx->h_pinned, (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the pinned buffer is reused below
+        if (host_in) {
+            const double *src = host_in + r0 * width;
+            if (array == PMF_ARR_COV) {
+                if (ctx->dtype == PMF_F64) pack_cov(src, (double *)ctx->h_pinned, nr, ctx->K, stride);
+                else pack_cov(src, (float *)ctx->h_pinned, nr, ctx->K, stride);
+            } else {
+                if (ctx->dtype == PMF_F64) pack_rows(src, (double *)ctx->h_pinned, nr, width, stride);
+                else pack_rows(src, (float *)ctx->h_pinned, nr, width, stride);
+            }
+            PMF_HIP_CHECK(hipMemcpyAsync(d_data, ctx->h_pinned, (size_t)(nr * row_bytes), hipMemcpyHostToDevice, ctx->stream));
+            launch_rows_copy<true>(ctx, ctx->arr[side][array], d_data, d_rows, nr, row_bytes);
+            PMF_HIP_CHECK(hipGetLastError());
+            PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else {
+            launch_rows_copy<false>(ctx, ctx->arr[side][array], d_data, d_rows, nr, row_bytes);
+            PMF_HIP_CHECK(hipGetLastError());
+            PMF_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, d_data, (size_t)(nr * row_bytes), hipMemcpyDeviceToHost, ctx->stream));
+            PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            pmf_unpack_rows(ctx, array, ctx->h_pinned, host_out + r0 * width, nr);
+        }
+    }
+    return PMF_OK;
+}
+
+extern "C" int pmf_get_array_rows(pmf_ctx *ctx, int side, int array, int64_t n, const int64_t *rows, double *host) {
+    return array_rows_impl(ctx, side, array, n, rows, nullptr, host, "pmf_get_array_rows");
+}
+
+extern "C" int pmf_set_array_rows(pmf_ctx *ctx, int side, int array, int64_t n, const int64_t *rows, const double *host) {
+    return array_rows_impl(ctx, side, array, n, rows, host, nullptr, "pmf_set_array_rows");
+}
+
 template <typename T>
 __global__ void cov_identity_kernel(T *cov, int64_t rows, int K, int stride, T scale) {
     int64_t total = rows * stride;

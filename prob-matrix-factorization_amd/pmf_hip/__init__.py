@@ -66,6 +66,8 @@ SIGNATURES = {
     "pmf_ctx_set_ratings": (C.c_int, [_p, C.c_int64, _i32p, _i32p, _f64p]),
     "pmf_set_array": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
     "pmf_get_array": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
+    "pmf_get_array_rows": (C.c_int, [_p, C.c_int, C.c_int, C.c_int64, _i64p, _f64p]),
+    "pmf_set_array_rows": (C.c_int, [_p, C.c_int, C.c_int, C.c_int64, _i64p, _f64p]),
     "pmf_set_cov_identity": (C.c_int, [_p, C.c_int, C.c_double]),
     "pmf_gamma_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
     "pmf_gamma_ext_sweep": (C.c_int, [_p, C.c_int, C.c_double, C.c_double]),

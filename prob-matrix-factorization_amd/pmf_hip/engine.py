@@ -161,6 +161,24 @@ class Context:
         check(self._lib.pmf_get_array(self._h, side, array, ptr(out, C.c_double)), "pmf_get_array")
         return out
 
+    def get_array_rows(self, side, array, rows):
+        """The given rows of `array` as host float64 (len(rows) x K, len(rows) or len(rows) x K x K):
+        `V_theta[rows]` without the 32 GB stack."""
+        r = np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1))
+        out = np.empty((len(r),) + self._host_shape(side, array)[1:], dtype=np.float64)
+        check(self._lib.pmf_get_array_rows(self._h, side, array, len(r), ptr(r, C.c_int64), ptr(out, C.c_double)),
+              "pmf_get_array_rows")
+        return out
+
+    def set_array_rows(self, side, array, rows, host):
+        r = np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1))
+        a = as_f64(host)
+        want = (len(r),) + self._host_shape(side, array)[1:]
+        if a.shape != want:
+            raise ValueError(f"array {array} of side {side}: expected shape {want}, got {a.shape}")
+        check(self._lib.pmf_set_array_rows(self._h, side, array, len(r), ptr(r, C.c_int64), ptr(a, C.c_double)),
+              "pmf_set_array_rows")
+
     def set_cov_identity(self, side, scale=1.0):
         check(self._lib.pmf_set_cov_identity(self._h, side, float(scale)), "pmf_set_cov_identity")
 

@@ -54,6 +54,25 @@ class GaussianHost(DeviceModel):
     def V_theta(self, value):
         self._V_theta = value
 
+    def V_theta_rows(self, user_ids):
+        """`V_theta[user_ids]` (len x K x K float64) read straight from the device's packed storage
+        (`pmf_get_array_rows`) -- what the reference's row indexing does (gaussian_mf_cavi_bias.py:157-162)
+        without materialising the whole stack.  After a sharded fit the ids must lie in `user_range`."""
+        ids = np.asarray(user_ids, dtype=np.int64).reshape(-1)
+        if self._V_theta is not None:
+            return np.asarray(self._V_theta)[ids - self.user_range[0]]
+        lo, hi = self.user_range
+        if len(ids) and (ids.min() < lo or ids.max() >= hi):
+            raise IndexError(f"V_theta_rows: user ids outside this rank's range [{lo}, {hi})")
+        return self._train_ctx().get_array_rows(USER, ARR_COV, ids - lo)
+
+    def V_beta_rows(self, item_ids):
+        """`V_beta[item_ids]` (len x K x K float64), same idea."""
+        ids = np.asarray(item_ids, dtype=np.int64).reshape(-1)
+        if self._V_beta is not None:
+            return np.asarray(self._V_beta)[ids]
+        return self._train_ctx().get_array_rows(ITEM, ARR_COV, ids)
+
     @property
     def V_beta(self):
         if self._V_beta is None and self._ctx is not None:

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(built.LIB_PATH)
     for name in _declared():
         assert hasattr(lib, name), name
-    assert built.load().pmf_abi_version() == 2
+    assert built.load().pmf_abi_version() == 3
 
 
 def test_no_gpu_is_an_error_not_a_fallback(built):

@@ -217,7 +217,7 @@ def cpu_baseline_c1(device=0):
     return out
 
 
-def cpu_baseline(workload, K, hp, device=0):
+def cpu_baseline(workload, K, hp, device=0, full=False):
     """The CPU oracle's per-row loop (the reference's loop structure) on a bounded sample of
     the same generator: ~10-30 s of CPU work with NumPy's default BLAS threading (`cores` = the
     threads its pool holds; the loop itself is interpreter-bound, one row at a time, as in the
@@ -230,8 +230,10 @@ def cpu_baseline(workload, K, hp, device=0):
     gauss = workload.startswith("gaussian_mf")
     if gauss:
         U, I, N = (20_000, 2_000, 1_100_000) if K <= 64 else (3_000, 300, 110_000)
+    elif full:
+        U, I, N = 1_000_000, 100_000, 50_000_000    # the C3 matrix itself
     else:
-        U, I, N = 300_000, 30_000, 16_500_000
+        U, I, N = 300_000, 30_000, 16_500_000       # the default sample: a third of C3's rows at C3's ratings per row
     u, i, r = synth_ratings(U, I, N, seed=7)
     u[0], i[0] = U - 1, I - 1
     (u, i, r), (vu, vi, vr) = train_val_split(u, i, r)
@@ -276,9 +278,12 @@ def cpu_baseline(workload, K, hp, device=0):
         pred_cpu = orc.predict_dot(st["E_theta"], st["E_beta"], vu, vi)
     rm_cpu, rm_gpu = orc.rmse(vy, pred_cpu), orc.rmse(vy, pred_gpu)
     model, logical = host_cpu()
+    scale_note = ("" if gauss else " -- the FULL C3 matrix (--cpu-full)" if full else
+                  " -- a bounded sample with C3's ratings per row; the per-row loop's rate does not depend on the row "
+                  "count, so this rate is also the extrapolated C3 rate (measured in full with --cpu-full)")
     out = {"value": N / dt, "unit": "ratings/s", "cores": blas_threads(), "kind": "port",
            "sample": f"1 iteration of the oracle's per-row NumPy loop, {U}x{I}, {N} ratings, K={K} "
-                     f"(same generator), {dt:.1f} s, default BLAS threading",
+                     f"(same generator), {dt:.1f} s, default BLAS threading" + scale_note,
            "cpu_model": model, "logical_cores": logical,
            "val_rmse_cpu": rm_cpu, "val_rmse_gpu_f32": rm_gpu, "val_rmse_abs_diff": abs(rm_cpu - rm_gpu)}
     if gauss and K == 64:
@@ -317,6 +322,9 @@ def main():
                     "N > 1 (default PMF_DIST_CHUNKS or by message size; 1 = accumulate, then all-reduce, then finalize)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0 (needs --transport hostshm)")
     ap.add_argument("--factors", type=int, default=None, help="exploration: override the workload's K")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="time the HPF cpu_baseline on the FULL C3 matrix (1M x 100k, 50M ratings, one iteration of the oracle's "
+                         "per-row loop: about a minute of CPU) instead of the default 300k x 30k x 16.5M sample")
     args = ap.parse_args()
 
     import pmf_hip
@@ -494,6 +502,17 @@ def main():
                 "bound": "cache_gather", "peak": peak, "frac": achieved / peak,
                 "peak_source": "pmf_prof_gather_ceiling: the sweep kernel's memory side alone on the same ratings/tables, "
                                "live in this run (user side %.3f ms, item side %.3f ms per launch)" % (ceil_ms[USER], ceil_ms[ITEM]),
+                "frac_is": "fraction of the gather-probe ceiling: the kernel against its own gather-only twin (a software probe "
+                           "that shares the kernel's access shape), NOT a hardware bound -- see hw_bound",
+                # hardware-derived bound beside it: the guide's measured chip-wide gather rates for random rows
+                # of an Infinity-Cache-resident table, per side by the size of the table that side gathers from
+                "hw_bound": (lambda rates: {
+                    "source": "MI355X_MICROARCH.md 'Indexed rows': uniformly random rows of a 38 MB table 8.6 TB/s, of a 151 MB "
+                              "table 7.4-7.9 TB/s (this workload: item table %.0f MB gathered by the user side, user table %.0f MB "
+                              "by the item side)" % (I * elem * K / 1e6, U_loc * elem * K / 1e6),
+                    "user_side_GBps": rates[USER], "item_side_GBps": rates[ITEM],
+                    "frac": sum(side_bytes[s_] / rates[s_] for s_ in (USER, ITEM)) / 1e6 / (dom_ms / steps)})(
+                        {USER: 8600.0 if I * elem * K <= 64e6 else 7650.0, ITEM: 8600.0 if U_loc * elem * K <= 64e6 else 7650.0}),
                 "algorithmic_GBps": achieved, "frac_of_hbm_peak_algorithmic": achieved / HBM_PEAK_GBS,
                 "compulsory_dram_GBps": dram / (dom_ms / steps * 1e-3) / 1e9,
                 "compulsory_dram_frac_of_hbm_peak": dram / (dom_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS})
@@ -590,9 +609,26 @@ def main():
             out["also"]["f64"] = {"gaussian_mf": brief(also["f64"]["gaussian_mf"], f"ratings/sec (epoch) Gaussian-MF K={K}", "f64"),
                                   "hpf_cavi": brief(also["f64"]["hpf_cavi"], f"ratings/sec (epoch) HPF-CAVI K={K}", "f64")}
     if not args.no_cpu_baseline and world == 1 and args.workload != "gaussian_mf_sgd":
-        out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank)
+        out["cpu_baseline"] = cpu_baseline(args.workload, K, hp, local_rank, full=args.cpu_full)
         if "hpf_cavi" in also:
-            out["also"]["hpf_cavi"]["cpu_baseline"] = cpu_baseline("hpf_cavi", K, WORKLOADS["hpf_cavi"]["hp"], local_rank)
+            out["also"]["hpf_cavi"]["cpu_baseline"] = cpu_baseline("hpf_cavi", K, WORKLOADS["hpf_cavi"]["hp"], local_rank,
+                                                                   full=args.cpu_full)
+    if also:
+        # LAST key of the line: every headline number in compact form, so that a record that keeps only the head and
+        # the tail of the line still carries them (`also` holds the detail)
+        def short(res):
+            rf = res["roofline"]
+            return {"value": float("%.4g" % res["value"]), "ms_per_step": float("%.4g" % res["ms_per_step"]),
+                    "roofline": {"bound": rf["bound"], "frac": float("%.3g" % rf["frac"]), "peak": float("%.4g" % rf["peak"])}}
+        summary = {}
+        if "hpf_cavi" in also:
+            summary["hpf_cavi_" + args.dtype] = short(also["hpf_cavi"])
+        if "f64" in also:
+            summary["gaussian_mf_f64"] = short(also["f64"]["gaussian_mf"])
+            summary["hpf_cavi_f64"] = short(also["f64"]["hpf_cavi"])
+        if "topk" in also:
+            summary["topk"] = short(also["topk"])
+        out["summary"] = summary
     print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()

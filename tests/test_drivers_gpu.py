@@ -101,6 +101,32 @@ def test_config5_poisson_k64_rmse_parity_with_the_reference(workdir, golden_dir)
     assert same >= 297
 
 
+def test_config5_poisson_k64_f64_identical_rankings_with_the_reference(workdir, golden_dir):
+    """The same run in the engine's float64 mode -- the reference's own arithmetic (poisson_mf_cavi.py:135-197 is
+    float64 NumPy) -- where "identical top-k item rankings" is asserted literally: after the 150 iterations the
+    top-10 list of every one of the 300 sampled users equals the reference's, in order, with NO tie tolerance;
+    test predictions and factor rows to rtol 1e-8 (the two differ by summation order only)."""
+    from src.models.poisson_mf_cavi import PoissonMFCAVI, PoissonMFCAVIConfig
+    import json
+    ref = np.load(os.path.join(golden_dir, "config5_poisson.npz"))
+    d = workdir / "data" / "processed"
+    tr = pd.concat([pd.read_csv(d / "interactions_train.csv"), pd.read_csv(d / "interactions_validation.csv")])
+    te = pd.read_csv(d / "interactions_test.csv")
+    assert (len(tr), len(te)) == (int(ref["n_train_rows"]), int(ref["n_test_rows"]))
+    cfg = json.loads(str(ref["cfg"]))
+    m = PoissonMFCAVI(PoissonMFCAVIConfig(verbose=False, **cfg), dtype="f64").fit(tr)
+    assert m.history_["iterations"] == 150
+    np.testing.assert_allclose(m.predict(te["u"].to_numpy(), te["i"].to_numpy()), ref["test_pred"], rtol=1e-8, atol=0)
+    assert abs(float(ref["test_rmse"]) - m.evaluate_rmse(te)) <= 1e-10
+    users = ref["users"]
+    np.testing.assert_allclose(m.E_theta[users], ref["E_theta_rows"], rtol=1e-8, atol=0)
+    assert abs(m.E_theta.sum() / float(ref["E_theta_sum"]) - 1) <= 1e-10 and abs(m.E_beta.sum() / float(ref["E_beta_sum"]) - 1) <= 1e-10
+    items, scores = m.top_k_items(users, 10)
+    assert len(users) == 300
+    np.testing.assert_array_equal(items, ref["top11"][:, :10])          # 300 / 300, in order, no tolerance
+    np.testing.assert_allclose(scores, ref["top11_scores"][:, :10], rtol=1e-8, atol=0)
+
+
 def test_tune_all_models_concurrent_trials_write_a_loadable_file(workdir, monkeypatch, capsys):
     """Random search with 4 concurrent engine contexts; the file it writes must
     round-trip through load_best_hyperparams into the config dataclasses."""

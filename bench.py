@@ -320,6 +320,9 @@ def main():
                     help="rccl = one rank per GPU over xGMI; hostshm = rehearsal transport for ranks sharing one GPU")
     ap.add_argument("--chunks", type=int, default=None, help="item row chunks of the pipelined item half-sweep at "
                     "N > 1 (default PMF_DIST_CHUNKS or by message size; 1 = accumulate, then all-reduce, then finalize)")
+    ap.add_argument("--exchange", choices=["auto", "allreduce", "scatter_gather"], default="auto",
+                    help="N > 1: how an item half-sweep's statistics travel -- all-reduce + every rank finalises every item, or "
+                         "reduce-scatter -> finalise 1/N of the items -> all-gather (auto: the latter for the Gaussian factor sweep)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: put every rank on GPU 0 (needs --transport hostshm)")
     ap.add_argument("--factors", type=int, default=None, help="exploration: override the workload's K")
     ap.add_argument("--cpu-full", action="store_true",
@@ -343,7 +346,9 @@ def main():
         if world != 1:
             raise SystemExit("--workload topk is a single-GPU measurement (queries are independent: replicas only)")
         return topk_bench(args, local_rank)
-    comm = pdist.init_from_env(device=local_rank, transport=args.transport) if world > 1 else None
+    if args.transport == "hostshm":
+        os.environ["PMF_COMM_TRANSPORT"] = "hostshm"     # the rehearsal transport lives in the test build of the library
+    comm = pdist.init_from_env(device=local_rank, transport=args.transport, exchange=args.exchange) if world > 1 else None
     strong = args.scaling == "strong"
 
     w = dict(WORKLOADS[args.workload])
@@ -576,10 +581,10 @@ def main():
         "config": {"workload": w["label"] + per_gpu + (" [--small]" if args.small else ""),
                    "n_users": users_total, "n_items": I, "ratings_total": ratings_total, "n_factors": K,
                    "ratings_on_rank0": N_loc, "users_on_rank0": U_loc,
-                   "parallelism": (f"user-range rating shards x{world} of the one matrix, item statistics all-reduced inside "
+                   "parallelism": (f"user-range rating shards x{world} of the one matrix, item statistics exchanged inside "
                                    f"libpmf_hip.so ({args.transport}), pipelined over {main_res['item_chunks']} item chunks"
                                    if world > 1 and strong else
-                                   f"one full-size user shard per rank x{world}, item statistics all-reduced inside "
+                                   f"one full-size user shard per rank x{world}, item statistics exchanged inside "
                                    f"libpmf_hip.so ({args.transport}), pipelined over {main_res['item_chunks']} item chunks"
                                    if world > 1 else "single GPU"),
                    "epoch_algorithmic_GB": main_res["epoch_algorithmic_GB"],
@@ -594,6 +599,7 @@ def main():
         "device_GB": main_res["device_GB"],
     }
     if world > 1:
+        out["config"]["exchange"] = args.exchange
         out["config"]["item_replicas_identical"] = main_res["item_replicas_identical"]
         if not main_res["item_replicas_identical"]:
             out["invalid"] = "replicated item state differs between ranks"

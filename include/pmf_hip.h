@@ -111,22 +111,6 @@ int pmf_ctx_destroy(pmf_ctx *ctx);
 int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream);
 int pmf_ctx_sync(pmf_ctx *ctx);
 
-/* HIP graphs (no reference counterpart).  At the reference's own problem sizes one iteration is a
- * handful of launch-bound kernels: the sweep calls issued between pmf_graph_begin and pmf_graph_end
- * are captured from the context's stream instead of being executed (their arguments are frozen),
- * and pmf_graph_launch replays them.  The sequence must have run once before it is captured (lazily
- * allocated arrays and scratch buffers cannot grow inside a capture), calls that synchronise or copy
- * to the host cannot be captured, and profiling brackets are skipped inside a capture.
- * pmf_graph_abort closes a capture after a failed call.  While a capture is open no other host thread may
- * issue default-stream work on the device (HIP refuses it).  Measured gain at the reference's sizes: none
- * (the iteration is bound by the kernels' dependent gather rounds); the model classes use it only with
- * PMF_HIP_GRAPH=1. */
-int pmf_graph_begin(pmf_ctx *ctx);
-int pmf_graph_end(pmf_ctx *ctx, int *graph_id);
-int pmf_graph_abort(pmf_ctx *ctx);
-int pmf_graph_launch(pmf_ctx *ctx, int graph_id);
-int pmf_graph_destroy(pmf_ctx *ctx, int graph_id);
-
 /* Row chunks (no reference counterpart; multi-GPU pipelining).  `n_chunks` equal row ranges of
  * one side; the *_accumulate / *_finalize calls of that side then act on the chunk chosen with
  * pmf_ctx_select_chunk (-1 = all rows, the default) -- they read and write only rows
@@ -240,7 +224,7 @@ int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, doubl
  * is replicated.  Once a context has a communicator (of any size), every ITEM-side half-sweep
  * (pmf_gamma_sweep, pmf_gauss_factor_sweep, pmf_gauss_bias_sweep, pmf_gauss_sgd_sweep with
  * side = PMF_SIDE_ITEM) runs inside the library as
- *     accumulate raw per-item sums over this rank's ratings  ->  all-reduce (sum)  ->  finalize
+ *     accumulate raw per-item sums over this rank's ratings  ->  exchange (sum over ranks)  ->  finalize
  * on a library-owned statistics buffer, pipelined over the item row chunks of pmf_ctx_set_row_chunks:
  * the all-reduce of chunk c runs on a second, high-priority HIP stream and its finalisation on a third
  * (ordered against the compute stream by events, never by the host) while chunk c+1 is accumulated.  Per-row arithmetic is that of
@@ -251,19 +235,38 @@ int pmf_gauss_bias_finalize(pmf_ctx *ctx, int side, const void *stats_dev, doubl
  *
  * pmf_comm_unique_id: 128 bytes from ncclGetUniqueId; rank 0 creates them and hands them to the other
  * ranks out of band (pmf_hip/dist.py: a file next to the launcher's rendezvous).  pmf_comm_init: RCCL
- * communicator over xGMI, collective (every rank must call it).  pmf_comm_init_hostshm: same
- * interface over POSIX shared memory for ranks that share ONE GPU -- a rehearsal transport for
- * one-GPU boxes (RCCL refuses two ranks per device), never a production path.  pmf_comm_attach lets a
+ * communicator over xGMI, collective (every rank must call it).  pmf_comm_attach lets a
  * second context of the same process and device share `owner`'s communicator; pmf_comm_destroy
- * detaches (the communicator goes with its last user; pmf_ctx_destroy detaches too). */
+ * detaches (the communicator goes with its last user; pmf_ctx_destroy detaches too).
+ *
+ * Exchange of a chunk's statistics (pmf_comm_set_exchange; the same mode on every rank):
+ *   PMF_EXCHANGE_ALLREDUCE       ncclAllReduce, then every rank finalises every row;
+ *   PMF_EXCHANGE_SCATTER_GATHER  ncclReduceScatter -> each rank finalises its 1/nranks of the chunk's rows ->
+ *                                ncclAllGather of the finalised state (the reference solves each row once,
+ *                                gaussian_mf_cavi_bias.py:170-201: so does the job as a whole, instead of
+ *                                nranks times).  Same wire bytes for the Gaussian factor sweep, whose state
+ *                                is as wide as its statistics; replicas stay bit-identical either way;
+ *   PMF_EXCHANGE_AUTO (default)  SCATTER_GATHER for pmf_gauss_factor_sweep on more than one rank (finalize =
+ *                                a K x K solve per row), ALLREDUCE for the sweeps whose finalize is
+ *                                element-wise.  Environment PMF_COMM_EXCHANGE=allreduce|scatter_gather
+ *                                sets the default of new contexts. */
 #define PMF_UNIQUE_ID_BYTES 128
 #define PMF_TRANSPORT_RCCL 0
-#define PMF_TRANSPORT_HOSTSHM 1
 #define PMF_OP_SUM 0
 #define PMF_OP_MAX 1
+#define PMF_EXCHANGE_AUTO 0
+#define PMF_EXCHANGE_ALLREDUCE 1
+#define PMF_EXCHANGE_SCATTER_GATHER 2
 int pmf_comm_unique_id(void *id_out);
 int pmf_comm_init(pmf_ctx *ctx, int nranks, int rank, const void *unique_id);
+int pmf_comm_set_exchange(pmf_ctx *ctx, int mode);
+#ifdef PMF_TEST_TRANSPORT
+/* TEST BUILDS ONLY (libpmf_hip_test.so, -DPMF_TEST_TRANSPORT; the product library does not export it): the same
+ * interface over POSIX shared memory for ranks that share ONE GPU -- a rehearsal transport for one-GPU
+ * boxes (RCCL refuses two ranks per device). */
+#define PMF_TRANSPORT_HOSTSHM 1
 int pmf_comm_init_hostshm(pmf_ctx *ctx, int nranks, int rank, const void *unique_id);
+#endif
 int pmf_comm_attach(pmf_ctx *ctx, pmf_ctx *owner);
 int pmf_comm_destroy(pmf_ctx *ctx);
 int pmf_comm_info(pmf_ctx *ctx, int *nranks, int *rank, int *transport);

@@ -7,21 +7,30 @@
 // compute stream, the library-owned statistics buffers, and the row-chunk pipeline that lets the
 // all-reduce of chunk c travel over xGMI while chunk c+1 is being accumulated.
 //
-// Two transports sit behind one small interface:
-//   RCCL     ncclAllReduce / ncclBroadcast on the collective stream (one rank per GPU; production);
-//   HOSTSHM  ranks of ONE GPU exchange through POSIX shared memory in stream order
-//            (hipLaunchHostFunc).  RCCL refuses two ranks on one device, so this is how the multi-rank
-//            code path -- chunk offsets, event ordering, the sharded fit -- is rehearsed on a
-//            one-GPU box.  It is a test transport: slow, node-local, never chosen by default.
-#include <errno.h>
-#include <fcntl.h>
+// Two exchanges of a chunk's statistics (pmf_comm_set_exchange):
+//   ALLREDUCE        ncclAllReduce, then EVERY rank finalises every row of the chunk;
+//   SCATTER_GATHER   ncclReduceScatter -> each rank finalises only ITS 1/N of the chunk's rows -> ncclAllGather of
+//                    the finalised state.  Same wire bytes for the Gaussian model (statistics and state are both
+//                    [Kp + Kpad] per row), 1/N of the K x K row solves per rank; every rank receives the same
+//                    finalised bytes, so the replicas stay bit-identical.
+//
+// The product library has ONE transport, RCCL (ncclAllReduce / ncclReduceScatter / ncclAllGather / ncclBroadcast on
+// the collective stream, one rank per GPU).  Built with -DPMF_TEST_TRANSPORT (libpmf_hip_test.so, tests only) it also
+// carries HOSTSHM: ranks of ONE GPU exchange through POSIX shared memory in stream order (hipLaunchHostFunc).  RCCL
+// refuses two ranks on one device, so this is how the multi-rank code path -- chunk offsets, event ordering, the
+// sharded fit, both exchanges -- is rehearsed on a one-GPU box.  Slow, node-local, never in the product build.
 #include <rccl/rccl.h>
-#include <sched.h>
+#include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
+#ifdef PMF_TEST_TRANSPORT
+#include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -40,10 +49,11 @@
 
 namespace {
 
+constexpr size_t kSmallBytes = 64u << 10;  // device / pinned buffer of the host-value collectives
+#ifdef PMF_TEST_TRANSPORT
 constexpr size_t kShmHeader = 4096;
 constexpr size_t kShmStage = 32u << 20;    // staging bytes per rank (messages travel in pieces of this size)
-constexpr double kShmTimeoutS = 120.0;     // a peer that never arrives must not hang the box
-constexpr size_t kSmallBytes = 64u << 10;  // device / pinned buffer of the host-value collectives
+constexpr double kShmTimeoutS = 120.0;     // default deadline of a hostshm rendezvous / barrier (PMF_COMM_TIMEOUT_S overrides)
 
 struct ShmHeader {
     std::atomic<int> count;
@@ -51,6 +61,7 @@ struct ShmHeader {
     std::atomic<int> attached;
     std::atomic<int> failed;
 };
+#endif
 
 double now_s() {
     timespec ts;
@@ -67,11 +78,13 @@ struct PmfComm {
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;             // the collectives' stream
     hipStream_t fin_stream = nullptr;         // finalize(c) runs here, beside the accumulation of later chunks
-    std::vector<hipEvent_t> ev_ready, ev_done, ev_fin;  // per row chunk: statistics ready / all-reduced / finalized
+    std::vector<hipEvent_t> ev_ready, ev_done, ev_fin, ev_gath;  // per row chunk: statistics ready / reduced / finalized / state gathered
     void *d_small = nullptr;                  // kSmallBytes, host-value collectives
     void *h_small = nullptr;                  // pinned twin
     bool failed = false;                      // a collective failed or timed out: every later call returns PMF_ECOMM
     double timeout_s = 1800.0;                // PMF_COMM_TIMEOUT_S
+    bool timeout_from_env = false;
+#ifdef PMF_TEST_TRANSPORT
     // HOSTSHM
     char shm_name[64] = "";
     void *shm = nullptr;
@@ -80,10 +93,18 @@ struct PmfComm {
     void *h_result = nullptr;                 // pinned, kShmStage: this rank's reduced piece
     ShmHeader *hdr() const { return (ShmHeader *)shm; }
     char *stage(int r) const { return (char *)shm + kShmHeader + (size_t)r * kShmStage; }
+    // deadline of a rendezvous / barrier: PMF_COMM_TIMEOUT_S when the environment sets it (a rank whose accumulate
+    // lags on a shared GPU must not poison the communicator at a fixed 120 s), else 120 s
+    double shm_deadline() const { return timeout_from_env && timeout_s > 0 ? timeout_s : kShmTimeoutS; }
+    bool peer_failed() const { return transport == PMF_TRANSPORT_HOSTSHM && shm && hdr()->failed.load(); }
+#else
+    bool peer_failed() const { return false; }
+#endif
 };
 
+#ifdef PMF_TEST_TRANSPORT
 // ---------------------------------------------------------------------------
-// HOSTSHM transport
+// HOSTSHM transport (test builds only)
 // ---------------------------------------------------------------------------
 namespace {
 
@@ -102,7 +123,7 @@ bool shm_barrier(PmfComm *cm) {
     while (h->generation.load() == gen) {
         if (h->failed.load()) return false;
         if ((++spins & 1023) == 0) {
-            if (now_s() - t0 > (cm->timeout_s > 0 ? std::min(kShmTimeoutS, cm->timeout_s) : kShmTimeoutS)) {
+            if (now_s() - t0 > cm->shm_deadline()) {
                 h->failed.store(1);
                 return false;
             }
@@ -114,23 +135,25 @@ bool shm_barrier(PmfComm *cm) {
 
 struct ShmOp {
     PmfComm *cm;
-    size_t bytes;
+    size_t bytes;    // bytes of the staged piece
+    size_t lo, hi;   // the part of the piece THIS rank reduces and takes back (all of it in an all-reduce; its
+                     // intersection with the rank's own slice in a reduce-scatter)
     int dtype;   // PMF_F32 / PMF_F64; -1 = broadcast
     int op;      // PMF_OP_SUM / PMF_OP_MAX
     int root;
 };
 
 template <typename T>
-void shm_reduce(PmfComm *cm, size_t n, int op) {
+void shm_reduce(PmfComm *cm, size_t lo, size_t hi, int op) {   // element range [lo, hi) of the staged piece
     T *out = (T *)cm->h_result;
     const T *first = (const T *)cm->stage(0);
-    for (size_t k = 0; k < n; ++k) out[k] = first[k];
+    for (size_t k = lo; k < hi; ++k) out[k] = first[k];
     for (int r = 1; r < cm->nranks; ++r) {   // rank order: every rank gets bit-identical sums
         const T *src = (const T *)cm->stage(r);
         if (op == PMF_OP_MAX)
-            for (size_t k = 0; k < n; ++k) out[k] = src[k] > out[k] ? src[k] : out[k];
+            for (size_t k = lo; k < hi; ++k) out[k] = src[k] > out[k] ? src[k] : out[k];
         else
-            for (size_t k = 0; k < n; ++k) out[k] += src[k];
+            for (size_t k = lo; k < hi; ++k) out[k] += src[k];
     }
 }
 
@@ -140,21 +163,26 @@ void shm_host_step(void *arg) {
     PmfComm *cm = o->cm;
     if (shm_barrier(cm)) {                     // every rank's piece is staged
         if (o->dtype < 0) memcpy(cm->h_result, cm->stage(o->root), o->bytes);
-        else if (o->dtype == PMF_F64) shm_reduce<double>(cm, o->bytes / 8, o->op);
-        else shm_reduce<float>(cm, o->bytes / 4, o->op);
+        else if (o->dtype == PMF_F64) shm_reduce<double>(cm, o->lo / 8, o->hi / 8, o->op);
+        else shm_reduce<float>(cm, o->lo / 4, o->hi / 4, o->op);
         (void)shm_barrier(cm);                 // nobody overwrites a staging area that is still being read
     }
     delete o;
 }
 
-int shm_collective(PmfComm *cm, const void *send, void *recv, size_t bytes, int dtype, int op, int root) {
+// `own_lo`, `own_hi`: the byte range of the message this rank keeps (reduce-scatter); the whole message otherwise
+int shm_collective(PmfComm *cm, const void *send, void *recv, size_t bytes, int dtype, int op, int root,
+                   size_t own_lo = 0, size_t own_hi = (size_t)-1) {
     PMF_REQUIRE(!cm->hdr()->failed.load(), PMF_ECOMM, "hostshm transport: a peer failed or timed out");
     const bool bcast = dtype < 0;
+    own_hi = std::min(own_hi, bytes);
     for (size_t off = 0; off < bytes; off += kShmStage) {
         const size_t n = std::min(kShmStage, bytes - off);
+        // this rank's part of the piece [off, off + n)
+        const size_t lo = std::min(std::max(own_lo, off), off + n) - off, hi = std::max(std::min(own_hi, off + n), off) - off;
         if (!bcast || cm->rank == root)
             PMF_HIP_CHECK(hipMemcpyAsync(cm->stage(cm->rank), (const char *)send + off, n, hipMemcpyDeviceToHost, cm->stream));
-        ShmOp *o = new (std::nothrow) ShmOp{cm, n, dtype, op, root};
+        ShmOp *o = new (std::nothrow) ShmOp{cm, n, lo, hi > lo ? hi : lo, dtype, op, root};
         PMF_REQUIRE(o, PMF_ENOMEM, "hostshm transport: out of host memory");
         hipError_t e = hipLaunchHostFunc(cm->stream, shm_host_step, o);
         if (e != hipSuccess) {
@@ -162,7 +190,10 @@ int shm_collective(PmfComm *cm, const void *send, void *recv, size_t bytes, int 
             pmf_set_error("hipLaunchHostFunc failed: %s", hipGetErrorString(e));
             return PMF_EHIP;
         }
-        PMF_HIP_CHECK(hipMemcpyAsync((char *)recv + off, cm->h_result, n, hipMemcpyHostToDevice, cm->stream));
+        if (bcast)
+            PMF_HIP_CHECK(hipMemcpyAsync((char *)recv + off, cm->h_result, n, hipMemcpyHostToDevice, cm->stream));
+        else if (hi > lo)
+            PMF_HIP_CHECK(hipMemcpyAsync((char *)recv + off + lo, (char *)cm->h_result + lo, hi - lo, hipMemcpyHostToDevice, cm->stream));
     }
     return PMF_OK;
 }
@@ -194,32 +225,50 @@ int shm_open_region(PmfComm *cm, const void *unique_id) {
                 close(fd);
                 fd = -1;
             }
-            PMF_REQUIRE(now_s() - t0 < kShmTimeoutS, PMF_ECOMM, "hostshm transport: rank 0 never created %s", cm->shm_name);
+            PMF_REQUIRE(now_s() - t0 < cm->shm_deadline(), PMF_ECOMM, "hostshm transport: rank 0 never created %s", cm->shm_name);
             usleep(2000);
         }
     }
+    // from here on every error exit of rank 0 removes the name: a failed launch must not leave
+    // 4 KB + nranks x 32 MB behind in /dev/shm
+    auto fail = [&](int code) {
+        if (cm->rank == 0) (void)shm_unlink(cm->shm_name);
+        return code;
+    };
     cm->shm = mmap(nullptr, cm->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (cm->shm == MAP_FAILED) {
         cm->shm = nullptr;
         pmf_set_error("mmap(%s) failed: %s", cm->shm_name, strerror(errno));
-        return PMF_ECOMM;
+        return fail(PMF_ECOMM);
     }
     // pinned staging makes the D2H / H2D legs truly asynchronous; pageable still works
     cm->shm_registered = hipHostRegister(cm->shm, cm->shm_bytes, hipHostRegisterDefault) == hipSuccess;
     if (!cm->shm_registered) (void)hipGetLastError();
-    PMF_HIP_CHECK(hipHostMalloc(&cm->h_result, kShmStage, hipHostMallocDefault));
+    hipError_t he = hipHostMalloc(&cm->h_result, kShmStage, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        pmf_set_error("hipHostMalloc failed: %s", hipGetErrorString(he));
+        return fail(PMF_EHIP);
+    }
     // rendezvous: the name can go once every rank has mapped the region
     cm->hdr()->attached.fetch_add(1);
     const double t0 = now_s();
     while (cm->hdr()->attached.load() < cm->nranks) {
-        PMF_REQUIRE(now_s() - t0 < kShmTimeoutS, PMF_ECOMM, "hostshm transport: %d of %d ranks attached",
-                    cm->hdr()->attached.load(), cm->nranks);
+        if (now_s() - t0 >= cm->shm_deadline()) {
+            pmf_set_error("hostshm transport: %d of %d ranks attached", cm->hdr()->attached.load(), cm->nranks);
+            cm->hdr()->failed.store(1);
+            return fail(PMF_ECOMM);
+        }
         usleep(1000);
     }
     if (cm->rank == 0) (void)shm_unlink(cm->shm_name);
     return PMF_OK;
 }
+
+}  // namespace
+#endif  // PMF_TEST_TRANSPORT
+
+namespace {
 
 // ---------------------------------------------------------------------------
 // transport-independent primitives (all asynchronous on cm->stream)
@@ -247,7 +296,7 @@ int comm_wait(PmfComm *cm, hipStream_t stream, const char *what) {
                 return PMF_ECOMM;
             }
         }
-        if (cm->transport == PMF_TRANSPORT_HOSTSHM && cm->hdr()->failed.load()) {
+        if (cm->peer_failed()) {
             cm->failed = true;
             pmf_set_error("%s: hostshm transport: a peer failed or timed out", what);
             return PMF_ECOMM;
@@ -270,8 +319,10 @@ int comm_wait(PmfComm *cm, hipStream_t stream, const char *what) {
 int comm_allreduce(PmfComm *cm, void *buf, size_t count, int dtype, int op) {
     if (count == 0) return PMF_OK;
     PMF_REQUIRE(!cm->failed, PMF_ECOMM, "the communicator has failed earlier (a collective error or timeout)");
+#ifdef PMF_TEST_TRANSPORT
     if (cm->transport == PMF_TRANSPORT_HOSTSHM)
         return shm_collective(cm, buf, buf, count * (dtype == PMF_F64 ? 8 : 4), dtype, op, 0);
+#endif
     PMF_NCCL_CHECK(ncclAllReduce(buf, buf, count, dtype == PMF_F64 ? ncclFloat64 : ncclFloat32,
                                  op == PMF_OP_MAX ? ncclMax : ncclSum, cm->nccl, cm->stream));
     return PMF_OK;
@@ -280,8 +331,44 @@ int comm_allreduce(PmfComm *cm, void *buf, size_t count, int dtype, int op) {
 int comm_broadcast(PmfComm *cm, const void *send, void *recv, size_t bytes, int root) {
     if (bytes == 0) return PMF_OK;
     PMF_REQUIRE(!cm->failed, PMF_ECOMM, "the communicator has failed earlier (a collective error or timeout)");
+#ifdef PMF_TEST_TRANSPORT
     if (cm->transport == PMF_TRANSPORT_HOSTSHM) return shm_collective(cm, send, recv, bytes, -1, 0, root);
+#endif
     PMF_NCCL_CHECK(ncclBroadcast(send, recv, bytes, ncclInt8, root, cm->nccl, cm->stream));
+    return PMF_OK;
+}
+
+// In-place sum reduce-scatter of nranks x `count` elements at `buf`: rank r ends with the sums of slice r
+// (elements [r count, (r + 1) count)); the other slices of its buffer are left undefined.
+int comm_reduce_scatter(PmfComm *cm, void *buf, size_t count, int dtype) {
+    if (count == 0) return PMF_OK;
+    PMF_REQUIRE(!cm->failed, PMF_ECOMM, "the communicator has failed earlier (a collective error or timeout)");
+    const size_t esz = dtype == PMF_F64 ? 8 : 4;
+#ifdef PMF_TEST_TRANSPORT
+    if (cm->transport == PMF_TRANSPORT_HOSTSHM)
+        return shm_collective(cm, buf, buf, (size_t)cm->nranks * count * esz, dtype, PMF_OP_SUM, 0,
+                              (size_t)cm->rank * count * esz, (size_t)(cm->rank + 1) * count * esz);
+#endif
+    PMF_NCCL_CHECK(ncclReduceScatter(buf, (char *)buf + (size_t)cm->rank * count * esz, count,
+                                     dtype == PMF_F64 ? ncclFloat64 : ncclFloat32, ncclSum, cm->nccl, cm->stream));
+    return PMF_OK;
+}
+
+// In-place all-gather of nranks slices of `bytes` bytes at `buf` (rank r contributes slice r).
+int comm_all_gather(PmfComm *cm, void *buf, size_t bytes) {
+    if (bytes == 0) return PMF_OK;
+    PMF_REQUIRE(!cm->failed, PMF_ECOMM, "the communicator has failed earlier (a collective error or timeout)");
+#ifdef PMF_TEST_TRANSPORT
+    if (cm->transport == PMF_TRANSPORT_HOSTSHM) {
+        for (int r = 0; r < cm->nranks; ++r) {
+            char *at = (char *)buf + (size_t)r * bytes;
+            int rc = shm_collective(cm, at, at, bytes, -1, 0, r);
+            if (rc) return rc;
+        }
+        return PMF_OK;
+    }
+#endif
+    PMF_NCCL_CHECK(ncclAllGather((char *)buf + (size_t)cm->rank * bytes, buf, bytes, ncclInt8, cm->nccl, cm->stream));
     return PMF_OK;
 }
 
@@ -293,17 +380,20 @@ void comm_free(PmfComm *cm) {
     for (auto &e : cm->ev_ready) (void)hipEventDestroy(e);
     for (auto &e : cm->ev_done) (void)hipEventDestroy(e);
     for (auto &e : cm->ev_fin) (void)hipEventDestroy(e);
+    for (auto &e : cm->ev_gath) (void)hipEventDestroy(e);
     if (cm->fin_stream) {
         (void)hipStreamSynchronize(cm->fin_stream);
         (void)hipStreamDestroy(cm->fin_stream);
     }
     if (cm->d_small) (void)hipFree(cm->d_small);
     if (cm->h_small) (void)hipHostFree(cm->h_small);
+#ifdef PMF_TEST_TRANSPORT
     if (cm->h_result) (void)hipHostFree(cm->h_result);
     if (cm->shm) {
         if (cm->shm_registered) (void)hipHostUnregister(cm->shm);
         munmap(cm->shm, cm->shm_bytes);
     }
+#endif
     if (cm->stream) (void)hipStreamDestroy(cm->stream);
     delete cm;
 }
@@ -320,7 +410,10 @@ int comm_create(pmf_ctx *ctx, int nranks, int rank, const void *unique_id, int t
     cm->rank = rank;
     cm->device = ctx->device;
     cm->transport = transport;
-    if (const char *e = getenv("PMF_COMM_TIMEOUT_S")) cm->timeout_s = atof(e);
+    if (const char *e = getenv("PMF_COMM_TIMEOUT_S")) {
+        cm->timeout_s = atof(e);
+        cm->timeout_from_env = true;
+    }
     int rc = PMF_OK;
     do {
         int lo = 0, hi = 0;   // collectives must not queue behind a 60 ms accumulate grid
@@ -344,7 +437,12 @@ int comm_create(pmf_ctx *ctx, int nranks, int rank, const void *unique_id, int t
             break;
         }
         if (transport == PMF_TRANSPORT_HOSTSHM) {
+#ifdef PMF_TEST_TRANSPORT
             rc = shm_open_region(cm, unique_id);
+#else
+            pmf_set_error("pmf_comm_init: this build of the library has no hostshm transport (tests use libpmf_hip_test.so)");
+            rc = PMF_EINVAL;
+#endif
         } else {
             ncclUniqueId id;
             static_assert(sizeof(id) == PMF_UNIQUE_ID_BYTES, "PMF_UNIQUE_ID_BYTES must match ncclUniqueId");
@@ -368,8 +466,8 @@ int comm_create(pmf_ctx *ctx, int nranks, int rank, const void *unique_id, int t
 
 int ensure_events(PmfComm *cm, size_t n) {
     while (cm->ev_fin.size() < n) {
-        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        for (int k = 0; k < 3; ++k) {
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 4; ++k) {
             hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
             if (e != hipSuccess) {
                 for (int q = 0; q < k; ++q) (void)hipEventDestroy(ev[q]);
@@ -380,6 +478,7 @@ int ensure_events(PmfComm *cm, size_t n) {
         cm->ev_ready.push_back(ev[0]);
         cm->ev_done.push_back(ev[1]);
         cm->ev_fin.push_back(ev[2]);
+        cm->ev_gath.push_back(ev[3]);
     }
     return PMF_OK;
 }
@@ -410,7 +509,6 @@ void pmf_comm_release(pmf_ctx *ctx) {
 int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out) {
     *out = nullptr;
     if (ctx->stats_bytes[which] < bytes) {
-        PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "a statistics buffer would have to grow inside a graph capture");
         if (ctx->d_stats[which]) {
             PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
             PMF_HIP_CHECK(hipStreamSynchronize(ctx->comm->stream));
@@ -427,43 +525,92 @@ int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out) {
     return PMF_OK;
 }
 
-// accumulate(c) -> all-reduce(c) -> finalize(c), pipelined over the row chunks of `side` (`chunked` = false: one
+// accumulate(c) -> exchange(c) -> finalize(c), pipelined over the row chunks of `side` (`chunked` = false: one
 // message for all rows).  `width` = statistics elements per row.  Three streams, ordered by events only:
 //   compute stream      accumulate(0), accumulate(1), ...                       (HBM-bound gathers)
-//   collective stream   all-reduce(c) as soon as accumulate(c) has finished      (xGMI)
-//   finalize stream     finalize(c) as soon as all-reduce(c) has landed          (row solves: VALU / LDS-bound)
+//   collective stream   the collectives of chunk c as soon as accumulate(c) has finished      (xGMI)
+//   finalize stream     finalize(c) as soon as chunk c's statistics have landed  (row solves: VALU / LDS-bound)
 // so the collective of chunk c AND its finalisation run beside the accumulation of the later chunks; the compute
-// stream only waits at the end, for the finalisations it has not already been overtaken by.  (Every rank
-// finalises every item: at BASELINE config C4 that is 1M 128 x 128 row solves per rank and iteration, about
-// 0.1 s -- hidden here instead of queued behind the last accumulate.)
+// stream only waits at the end, for what it has not already been overtaken by.
+//
+// ALLREDUCE exchange: ncclAllReduce of the chunk's slice, then every rank finalises every row of it (at BASELINE
+// config C4 that is 1M 128 x 128 row solves per rank and iteration).
+// SCATTER_GATHER exchange (`ex.arrays` = the state arrays finalize writes): the chunk's rows are cut into nranks equal
+// sub-ranges of `per` rows (the < nranks rows left over are all-reduced and finalised by everybody);
+// ncclReduceScatter leaves rank r with the sums of sub-range r, rank r finalises those rows only, and one
+// ncclAllGather per state array hands the finalised rows to everybody -- each rank solves 1/N of the rows and all
+// ranks hold the same finalised bytes.  Collective stream order (the same on every rank): RS(0), RS(1), AG(0),
+// RS(2), AG(1), ... so the reduce-scatter of chunk c + 1 never queues behind the finalisation of chunk c.
 int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool chunked,
-                        const std::function<int()> &accumulate, const std::function<int()> &finalize) {
+                        const std::function<int()> &accumulate, const std::function<int()> &finalize,
+                        const PmfExchange &ex) {
     PmfComm *cm = ctx->comm;
-    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "a multi-GPU half-sweep cannot be captured into a HIP graph");
     const int n = chunked ? ctx->n_chunks[side] : 1;
     int rc = ensure_events(cm, (size_t)n);
     if (rc) return rc;
+    const bool sg = ex.n_arrays > 0 && (ctx->exchange == PMF_EXCHANGE_SCATTER_GATHER ||
+                                        (ctx->exchange == PMF_EXCHANGE_AUTO && ex.prefer_scatter && cm->nranks > 1));
+    const int64_t N = cm->nranks;
     const int saved = ctx->cur_chunk[side];
     hipStream_t const compute = ctx->stream;
     auto fail = [&](const char *what, hipError_t e) {
         pmf_set_error("%s failed: %s", what, hipGetErrorString(e));
         return PMF_EHIP;
     };
-    int issued = 0;   // chunks whose finalize has been queued
+    auto chunk_rows = [&](int c, int64_t &r0, int64_t &r1) {
+        r0 = chunked ? pmf_chunk_row0(ctx, side, c) : 0;
+        r1 = chunked ? pmf_chunk_row0(ctx, side, c + 1) : ctx->rows[side];
+    };
+    // finalize rows [a, b) of the selected chunk on the finalize stream
+    auto finalize_rows = [&](int64_t a, int64_t b) {
+        if (b <= a) return (int)PMF_OK;
+        ctx->fin_row0 = a;
+        ctx->fin_row1 = b;
+        ctx->stream = cm->fin_stream;
+        const int r = finalize();
+        ctx->stream = compute;
+        ctx->fin_row0 = ctx->fin_row1 = -1;
+        return r;
+    };
+    // all-gather of chunk c's finalised state (SCATTER_GATHER), behind its finalisation
+    auto gather = [&](int c) {
+        int64_t r0, r1;
+        chunk_rows(c, r0, r1);
+        const int64_t per = (r1 - r0) / N;
+        hipError_t e = hipStreamWaitEvent(cm->stream, cm->ev_fin[(size_t)c], 0);
+        if (e != hipSuccess) return fail("event ordering of the state all-gather", e);
+        int r = PMF_OK;
+        pmf_prof_begin_on(ctx, PMF_KERNEL_COMM_ALLREDUCE, cm->stream);
+        for (int k = 0; k < ex.n_arrays && !r && per > 0; ++k) {
+            int host_width, stride;
+            pmf_array_shape(ctx, ex.arrays[k], &host_width, &stride);
+            const size_t row_bytes = (size_t)stride * ctx->elem;
+            r = comm_all_gather(cm, (char *)ctx->arr[side][ex.arrays[k]] + (size_t)r0 * row_bytes, (size_t)per * row_bytes);
+        }
+        pmf_prof_end_on(ctx, cm->stream);
+        if (r) return r;
+        e = hipEventRecord(cm->ev_gath[(size_t)c], cm->stream);
+        return e == hipSuccess ? (int)PMF_OK : fail("hipEventRecord", e);
+    };
+    int issued = 0;     // chunks whose finalize has been queued
+    int gathered = 0;   // chunks whose all-gather has been queued
     for (int c = 0; c < n && !rc; ++c) {
         ctx->cur_chunk[side] = chunked ? c : -1;
         if ((rc = accumulate())) break;
-        const int64_t r0 = chunked ? pmf_chunk_row0(ctx, side, c) : 0;
-        const int64_t r1 = chunked ? pmf_chunk_row0(ctx, side, c + 1) : ctx->rows[side];
+        int64_t r0, r1;
+        chunk_rows(c, r0, r1);
         hipError_t e = hipEventRecord(cm->ev_ready[(size_t)c], compute);
         if (e == hipSuccess) e = hipStreamWaitEvent(cm->stream, cm->ev_ready[(size_t)c], 0);
         if (e != hipSuccess) {
-            rc = fail("event ordering of the item all-reduce", e);
+            rc = fail("event ordering of the item collective", e);
             break;
         }
+        const int64_t per = sg ? (r1 - r0) / N : 0, main = per * N;   // rows [r0, r0 + main) are scattered
         pmf_prof_begin_on(ctx, PMF_KERNEL_COMM_ALLREDUCE, cm->stream);
-        rc = comm_allreduce(cm, (char *)stats + (size_t)r0 * width * ctx->elem, (size_t)(r1 - r0) * width, ctx->dtype,
-                            PMF_OP_SUM);
+        if (per > 0) rc = comm_reduce_scatter(cm, (char *)stats + (size_t)r0 * width * ctx->elem, (size_t)per * width, ctx->dtype);
+        if (!rc)
+            rc = comm_allreduce(cm, (char *)stats + (size_t)(r0 + main) * width * ctx->elem, (size_t)(r1 - r0 - main) * width,
+                                ctx->dtype, PMF_OP_SUM);
         pmf_prof_end_on(ctx, cm->stream);
         if (rc) break;
         e = hipEventRecord(cm->ev_done[(size_t)c], cm->stream);
@@ -472,9 +619,9 @@ int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool 
             rc = fail("event ordering of the finalize", e);
             break;
         }
-        ctx->stream = cm->fin_stream;     // the finalize kernels of this chunk go to the finalize stream
-        rc = finalize();
-        ctx->stream = compute;
+        // the finalize kernels of this chunk go to the finalize stream: this rank's sub-range, then the rows all ranks share
+        if (per > 0) rc = finalize_rows(r0 + cm->rank * per, r0 + (cm->rank + 1) * per);
+        if (!rc) rc = finalize_rows(r0 + main, r1);
         if (rc) break;
         e = hipEventRecord(cm->ev_fin[(size_t)c], cm->fin_stream);
         if (e != hipSuccess) {
@@ -482,17 +629,27 @@ int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool 
             break;
         }
         issued = c + 1;
+        if (sg && c > 0) {   // the previous chunk's gather goes behind this chunk's reduce-scatter
+            if ((rc = gather(c - 1))) break;
+            gathered = c;
+        }
     }
-    // the next half-sweep reads the finalised rows: the compute stream joins the finalize stream here.  Its idle
-    // time in these waits is the communication + finalisation that accumulation did not hide.
+    if (sg && !rc && issued == n) {
+        rc = gather(n - 1);
+        if (!rc) gathered = n;
+    }
+    // the next half-sweep reads the finalised rows: the compute stream joins the finalize (and gather) work here.
+    // Its idle time in these waits is the communication + finalisation that accumulation did not hide.
     for (int c = 0; c < issued; ++c) {
         pmf_prof_begin_on(ctx, PMF_KERNEL_COMM_WAIT, compute);
         hipError_t e = hipStreamWaitEvent(compute, cm->ev_fin[(size_t)c], 0);
+        if (e == hipSuccess && c < gathered) e = hipStreamWaitEvent(compute, cm->ev_gath[(size_t)c], 0);
         pmf_prof_end_on(ctx, compute);
         if (e != hipSuccess && !rc) rc = fail("hipStreamWaitEvent", e);
     }
     ctx->stream = compute;
     ctx->cur_chunk[side] = saved;
+    ctx->fin_row0 = ctx->fin_row1 = -1;
     if (rc) {   // leave nothing half-ordered behind an error
         (void)hipStreamSynchronize(cm->stream);
         (void)hipStreamSynchronize(cm->fin_stream);
@@ -516,8 +673,18 @@ extern "C" int pmf_comm_init(pmf_ctx *ctx, int nranks, int rank, const void *uni
     return comm_create(ctx, nranks, rank, unique_id, PMF_TRANSPORT_RCCL);
 }
 
+#ifdef PMF_TEST_TRANSPORT
 extern "C" int pmf_comm_init_hostshm(pmf_ctx *ctx, int nranks, int rank, const void *unique_id) {
     return comm_create(ctx, nranks, rank, unique_id, PMF_TRANSPORT_HOSTSHM);
+}
+#endif
+
+extern "C" int pmf_comm_set_exchange(pmf_ctx *ctx, int mode) {
+    PMF_REQUIRE(ctx != nullptr, PMF_EINVAL, "pmf_comm_set_exchange: null context");
+    PMF_REQUIRE(mode == PMF_EXCHANGE_AUTO || mode == PMF_EXCHANGE_ALLREDUCE || mode == PMF_EXCHANGE_SCATTER_GATHER, PMF_EINVAL,
+                "pmf_comm_set_exchange: bad mode %d", mode);
+    ctx->exchange = mode;
+    return PMF_OK;
 }
 
 extern "C" int pmf_comm_attach(pmf_ctx *ctx, pmf_ctx *owner) {
@@ -566,8 +733,7 @@ extern "C" int pmf_comm_allreduce_host(pmf_ctx *ctx, double *values, int64_t n, 
         if (rc) return rc;
         PMF_HIP_CHECK(hipMemcpyAsync(cm->h_small, cm->d_small, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, cm->stream));
         if ((rc = comm_wait(cm, cm->stream, "pmf_comm_allreduce_host"))) return rc;
-        PMF_REQUIRE(cm->transport != PMF_TRANSPORT_HOSTSHM || !cm->hdr()->failed.load(), PMF_ECOMM,
-                    "hostshm transport: a peer failed or timed out");
+        PMF_REQUIRE(!cm->peer_failed(), PMF_ECOMM, "hostshm transport: a peer failed or timed out");
         memcpy(values + at, cm->h_small, (size_t)m * sizeof(double));
     }
     return PMF_OK;
@@ -628,7 +794,6 @@ extern "C" int pmf_comm_gather_user_rows(pmf_ctx *ctx, int array, const int64_t 
             pmf_unpack_rows(ctx, array, ctx->h_pinned, host_full + (bounds[r] + r0) * width, nr);
         }
     }
-    PMF_REQUIRE(cm->transport != PMF_TRANSPORT_HOSTSHM || !cm->hdr()->failed.load(), PMF_ECOMM,
-                "hostshm transport: a peer failed or timed out");
+    PMF_REQUIRE(!cm->peer_failed(), PMF_ECOMM, "hostshm transport: a peer failed or timed out");
     return PMF_OK;
 }

@@ -45,8 +45,6 @@ extern "C" int pmf_device_count(int *count) {
 // ---------------------------------------------------------------------------
 int pmf_dev_alloc(pmf_ctx *ctx, void **p, size_t bytes) {
     *p = nullptr;
-    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL,
-                "a device array would have to be allocated inside pmf_graph_begin / pmf_graph_end: run the sequence once before capturing it");
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {
@@ -65,8 +63,6 @@ void pmf_dev_free(pmf_ctx *ctx, void *p, size_t bytes) {
 
 static int grow(pmf_ctx *ctx, void **p, size_t *have, size_t want) {
     if (*have >= want) return PMF_OK;
-    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL,
-                "a scratch buffer would have to grow inside pmf_graph_begin / pmf_graph_end: run the sequence once before capturing it");
     if (*p) {
         PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         pmf_dev_free(ctx, *p, *have);
@@ -188,6 +184,10 @@ extern "C" int pmf_ctx_create(int device, int64_t n_users, int64_t n_items, int 
     ctx->gauss_unfused = getenv("PMF_GAUSS_UNFUSED") != nullptr;
     ctx->gauss_lds_solve = getenv("PMF_GAUSS_LDS_SOLVE") != nullptr;
     ctx->topk_two_phase = getenv("PMF_TOPK_TWO_PHASE") != nullptr;
+    if (const char *ex = getenv("PMF_COMM_EXCHANGE")) {
+        if (!strcmp(ex, "allreduce")) ctx->exchange = PMF_EXCHANGE_ALLREDUCE;
+        else if (!strcmp(ex, "scatter_gather")) ctx->exchange = PMF_EXCHANGE_SCATTER_GATHER;
+    }
     *out = ctx;
     return PMF_OK;
 }
@@ -241,8 +241,6 @@ extern "C" int pmf_ctx_destroy(pmf_ctx *ctx) {
         (void)hipEventDestroy(r.b);
     }
     for (auto &e : ctx->prof_pool) (void)hipEventDestroy(e);
-    for (auto &g : ctx->graphs)
-        if (g) (void)hipGraphExecDestroy(g);
     free_index(ctx);
     free_eval(ctx);
     for (int s = 0; s < 2; ++s)
@@ -261,82 +259,6 @@ extern "C" int pmf_ctx_set_stream(pmf_ctx *ctx, void *hip_stream) {
     PMF_HIP_CHECK(hipSetDevice(ctx->device));
     PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-    return PMF_OK;
-}
-
-// ---------------------------------------------------------------------------
-// HIP graphs: at the reference's problem sizes an iteration is a handful of launch-bound kernels;
-// a sequence of sweep calls can be captured once from the context's stream and replayed
-// ---------------------------------------------------------------------------
-extern "C" int pmf_graph_begin(pmf_ctx *ctx) {
-    CHECK_CTX(ctx, "pmf_graph_begin");
-    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "pmf_graph_begin: a capture is already open");
-    PMF_HIP_CHECK(hipSetDevice(ctx->device));
-    PMF_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    ctx->capturing = true;
-    return PMF_OK;
-}
-
-static int end_capture(pmf_ctx *ctx, hipGraph_t *graph) {
-    ctx->capturing = false;
-    PMF_HIP_CHECK(hipStreamEndCapture(ctx->stream, graph));
-    return PMF_OK;
-}
-
-extern "C" int pmf_graph_abort(pmf_ctx *ctx) {
-    CHECK_CTX(ctx, "pmf_graph_abort");
-    if (!ctx->capturing) return PMF_OK;
-    hipGraph_t graph = nullptr;
-    int rc = end_capture(ctx, &graph);
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    return rc == PMF_OK ? PMF_OK : PMF_OK;   // the stream is usable again either way
-}
-
-extern "C" int pmf_graph_end(pmf_ctx *ctx, int *graph_id) {
-    CHECK_CTX(ctx, "pmf_graph_end");
-    PMF_REQUIRE(graph_id, PMF_EINVAL, "pmf_graph_end: null argument");
-    PMF_REQUIRE(ctx->capturing, PMF_EINVAL, "pmf_graph_end: no capture is open");
-    hipGraph_t graph = nullptr;
-    int rc = end_capture(ctx, &graph);
-    if (rc) return rc;
-    hipGraphExec_t exec = nullptr;
-    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) {
-        pmf_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
-        return PMF_EHIP;
-    }
-    try {
-        ctx->graphs.push_back(exec);
-    } catch (const std::bad_alloc &) {
-        (void)hipGraphExecDestroy(exec);
-        pmf_set_error("pmf_graph_end: out of host memory");
-        return PMF_ENOMEM;
-    }
-    *graph_id = (int)ctx->graphs.size() - 1;
-    return PMF_OK;
-}
-
-extern "C" int pmf_graph_launch(pmf_ctx *ctx, int graph_id) {
-    CHECK_CTX(ctx, "pmf_graph_launch");
-    PMF_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size() && ctx->graphs[(size_t)graph_id], PMF_EINVAL,
-                "pmf_graph_launch: unknown graph %d", graph_id);
-    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "pmf_graph_launch: a capture is open");
-    PMF_HIP_CHECK(hipSetDevice(ctx->device));
-    PMF_HIP_CHECK(hipGraphLaunch(ctx->graphs[(size_t)graph_id], ctx->stream));
-    return PMF_OK;
-}
-
-extern "C" int pmf_graph_destroy(pmf_ctx *ctx, int graph_id) {
-    CHECK_CTX(ctx, "pmf_graph_destroy");
-    PMF_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size(), PMF_EINVAL, "pmf_graph_destroy: unknown graph %d",
-                graph_id);
-    if (ctx->graphs[(size_t)graph_id]) {
-        PMF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipGraphExecDestroy(ctx->graphs[(size_t)graph_id]);
-        ctx->graphs[(size_t)graph_id] = nullptr;
-    }
     return PMF_OK;
 }
 
@@ -445,6 +367,14 @@ PmfTaskView pmf_task_view(const pmf_ctx *ctx, int side, const PmfTaskList &tl, b
     const int c = select ? ctx->cur_chunk[side] : -1;
     PmfTaskView v;
     v.n_slots = tl.n_slots;
+    // a finalize window (pmf_comm_half_sweep, SCATTER_GATHER exchange) narrows the ROW RANGE of the view; the
+    // finalize-from-statistics launches use nothing else of it
+    auto clip = [&](PmfTaskView &w) {
+        if (select && ctx->fin_row0 >= 0) {
+            w.row0 = std::max(w.row0, ctx->fin_row0);
+            w.row1 = std::max(w.row0, std::min(w.row1, ctx->fin_row1));
+        }
+    };
     if (c < 0 || tl.task_off.empty()) {
         v.d_tasks = tl.d_tasks;
         v.d_split = tl.d_split;
@@ -455,6 +385,7 @@ PmfTaskView pmf_task_view(const pmf_ctx *ctx, int side, const PmfTaskList &tl, b
         v.row1 = ctx->rows[side];
         v.d_nonempty = ix.d_nonempty;
         v.n_nonempty = ix.n_nonempty;
+        clip(v);
         return v;
     }
     const size_t g = (size_t)c;
@@ -467,6 +398,7 @@ PmfTaskView pmf_task_view(const pmf_ctx *ctx, int side, const PmfTaskList &tl, b
     v.row1 = pmf_chunk_row0(ctx, side, c + 1);
     v.d_nonempty = ix.d_nonempty + ix.nonempty_off[g];
     v.n_nonempty = ix.nonempty_off[g + 1] - ix.nonempty_off[g];
+    clip(v);
     return v;
 }
 
@@ -974,7 +906,7 @@ static hipEvent_t take_event(pmf_ctx *ctx) {
 }
 
 void pmf_prof_begin_on(pmf_ctx *ctx, int kernel, hipStream_t stream) {
-    if (!ctx->prof || ctx->capturing) return;
+    if (!ctx->prof) return;
     pmf_ctx::ProfRec r;
     r.a = take_event(ctx);
     r.b = take_event(ctx);
@@ -984,7 +916,7 @@ void pmf_prof_begin_on(pmf_ctx *ctx, int kernel, hipStream_t stream) {
 }
 
 void pmf_prof_end_on(pmf_ctx *ctx, hipStream_t stream) {
-    if (!ctx->prof || ctx->capturing || ctx->prof_pending.empty()) return;
+    if (!ctx->prof || ctx->prof_pending.empty()) return;
     (void)hipEventRecord(ctx->prof_pending.back().b, stream);
 }
 

@@ -420,9 +420,23 @@ static int run_gamma_dist(pmf_ctx *ctx, int side, double shape_prior, double rat
     void *stats = nullptr;
     int rc = pmf_comm_stats(ctx, 0, (size_t)ctx->rows[side] * width * sizeof(T), &stats);
     if (rc) return rc;
+    // finalize is element-wise (cheap) and writes 3 Kpad + 2 values per row for 2 Kpad of statistics: the plain
+    // all-reduce is the default exchange here
+    PmfExchange ex;
+    ex.arrays[ex.n_arrays++] = PMF_ARR_FACTOR;
+    ex.arrays[ex.n_arrays++] = PMF_ARR_SHAPE;
+    ex.arrays[ex.n_arrays++] = PMF_ARR_RATE;
+    if (hierarchical) {
+        ex.arrays[ex.n_arrays++] = PMF_ARR_PRIOR_RATE;
+        ex.arrays[ex.n_arrays++] = PMF_ARR_HYPER_RATE;
+    }
+    if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_SHAPE))) return rc;   // (the gathers address them before finalize runs)
+    if ((rc = pmf_alloc_array(ctx, side, PMF_ARR_RATE))) return rc;
+    if (hierarchical && (rc = pmf_alloc_array(ctx, side, PMF_ARR_HYPER_RATE))) return rc;
     return pmf_comm_half_sweep(
         ctx, side, width, stats, true, [&] { return run_gamma<T>(ctx, side, 1, stats, 0, 0, 0, 0, 0); },
-        [&] { return run_gamma<T>(ctx, side, 2, stats, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior); });
+        [&] { return run_gamma<T>(ctx, side, 2, stats, shape_prior, rate_prior, hierarchical, hyper_shape, hyper_rate_prior); },
+        ex);
 }
 
 extern "C" int pmf_gamma_sweep(pmf_ctx *ctx, int side, double shape_prior, double rate_prior,
@@ -468,7 +482,6 @@ extern "C" int pmf_gamma_finalize(pmf_ctx *ctx, int side, const void *stats_dev,
 extern "C" int pmf_prof_gather_ceiling(pmf_ctx *ctx, int side, int repeats, double *ms_per_launch) {
     GAMMA_PROLOGUE("pmf_prof_gather_ceiling");
     PMF_REQUIRE(ms_per_launch != nullptr && repeats >= 1, PMF_EINVAL, "pmf_prof_gather_ceiling: bad arguments");
-    PMF_REQUIRE(!ctx->capturing, PMF_EINVAL, "pmf_prof_gather_ceiling: a capture is open");
     hipEvent_t a = nullptr, b = nullptr;
     PMF_HIP_CHECK(hipEventCreate(&a));
     hipError_t e = hipEventCreate(&b);

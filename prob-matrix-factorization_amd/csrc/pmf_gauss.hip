@@ -1600,13 +1600,19 @@ static int run_factor_dist(pmf_ctx *ctx, int side, double sigma2, double eta2) {
     void *stats = nullptr;
     int rc = pmf_comm_stats(ctx, 0, (size_t)ctx->rows[side] * width * sizeof(T), &stats);
     if (rc) return rc;
+    // finalize = one K x K solve per row, and the finalised state ([Kp + Kpad] per row) is as wide as the statistics:
+    // reduce-scatter -> solve 1/N of the rows -> all-gather moves the same bytes and divides the solves by N
+    PmfExchange ex;
+    ex.prefer_scatter = true;
+    ex.arrays[ex.n_arrays++] = PMF_ARR_FACTOR;
+    ex.arrays[ex.n_arrays++] = PMF_ARR_COV;
     return pmf_comm_half_sweep(
         ctx, side, width, stats, true,
         [&] {
             bool fused = false;
             return run_factor_accumulate<T>(ctx, side, stats, 1.0, 1.0, &fused);
         },
-        [&] { return run_factor_solve<T>(ctx, side, stats, sigma2, eta2); });
+        [&] { return run_factor_solve<T>(ctx, side, stats, sigma2, eta2); }, ex);
 }
 
 extern "C" int pmf_gauss_factor_sweep(pmf_ctx *ctx, int side, double sigma2, double eta2) {
@@ -1720,9 +1726,11 @@ static int run_bias_dist(pmf_ctx *ctx, int side, double sigma2, double eta_bias2
     void *stats = nullptr;   // [rows x 2]: latency-bound, one message
     int rc = pmf_comm_stats(ctx, 1, (size_t)ctx->rows[side] * 2 * sizeof(T), &stats);
     if (rc) return rc;
+    PmfExchange ex;
+    ex.arrays[ex.n_arrays++] = PMF_ARR_BIAS;
     return pmf_comm_half_sweep(
         ctx, side, 2, stats, false, [&] { return run_bias<T>(ctx, side, 1, stats, 1, 1); },
-        [&] { return run_bias<T>(ctx, side, 2, stats, sigma2, eta_bias2); });
+        [&] { return run_bias<T>(ctx, side, 2, stats, sigma2, eta_bias2); }, ex);
 }
 
 extern "C" int pmf_gauss_bias_sweep(pmf_ctx *ctx, int side, double sigma2, double eta_bias2) {

@@ -11,6 +11,10 @@
 
 #include "pmf_hip.h"
 
+#ifndef PMF_TRANSPORT_HOSTSHM
+#define PMF_TRANSPORT_HOSTSHM 1   // declared by the header in test builds only (-DPMF_TEST_TRANSPORT)
+#endif
+
 #define PMF_WAVE 64
 #define PMF_VEC 4               // elements per lane access (16 B fp32 / 32 B fp64)
 #define PMF_RATE_FLOOR 1e-10    // hpf_cavi.py:141
@@ -119,6 +123,10 @@ struct pmf_ctx {
 
     int n_chunks[2] = {1, 1};    // row chunks per side (multi-GPU pipelining of a half-sweep)
     int cur_chunk[2] = {-1, -1};  // chunk the accumulate / finalize calls act on; -1 = all rows
+    // row window of a finalize-from-statistics call inside pmf_comm_half_sweep (the sub-range of a chunk this rank
+    // owns under the SCATTER_GATHER exchange); -1 = the whole selected chunk
+    int64_t fin_row0 = -1, fin_row1 = -1;
+    int exchange = PMF_EXCHANGE_AUTO;   // pmf_comm_set_exchange
 
     void *arr[2][PMF_ARR_COUNT] = {};
     PmfSideIndex index[2];
@@ -146,10 +154,6 @@ struct pmf_ctx {
     struct PmfComm *comm = nullptr;
     void *d_stats[2] = {nullptr, nullptr};
     size_t stats_bytes[2] = {0, 0};
-
-    // HIP graphs captured from sequences of sweep calls (pmf_graph_begin / _end)
-    bool capturing = false;
-    std::vector<hipGraphExec_t> graphs;
 
     bool prof = false;
     struct ProfRec {
@@ -202,8 +206,16 @@ int pmf_comm_stats(pmf_ctx *ctx, int which, size_t bytes, void **out);
 // a deadline (PMF_COMM_TIMEOUT_S, default 1800; 0 = wait for ever), so that a peer that died or never arrived
 // ends in PMF_ECOMM on the surviving ranks instead of a hang.
 int pmf_comm_wait_stream(pmf_ctx *ctx, hipStream_t stream, const char *what);
+// what a half-sweep's finalize writes (the arrays of `side` the SCATTER_GATHER exchange all-gathers) and whether
+// PMF_EXCHANGE_AUTO should pick that exchange for it (true where finalize is expensive: the Gaussian row solves)
+struct PmfExchange {
+    bool prefer_scatter = false;
+    int n_arrays = 0;
+    int arrays[6] = {0, 0, 0, 0, 0, 0};
+};
 int pmf_comm_half_sweep(pmf_ctx *ctx, int side, size_t width, void *stats, bool chunked,
-                        const std::function<int()> &accumulate, const std::function<int()> &finalize);
+                        const std::function<int()> &accumulate, const std::function<int()> &finalize,
+                        const PmfExchange &ex);
 
 // profiling brackets (the *_on forms time work on another stream than the context's)
 void pmf_prof_begin(pmf_ctx *ctx, int kernel);

@@ -270,10 +270,13 @@ extern "C" int pmf_gauss_sgd_sweep(pmf_ctx *ctx, int side, double lr, double sig
         void *stats = nullptr;
         int rc = pmf_comm_stats(ctx, 0, (size_t)ctx->rows[side] * width * ctx->elem, &stats);
         if (rc) return rc;
+        PmfExchange ex;
+        ex.arrays[ex.n_arrays++] = PMF_ARR_FACTOR;
+        if (ctx->arr[0][PMF_ARR_BIAS] != nullptr && ctx->arr[1][PMF_ARR_BIAS] != nullptr) ex.arrays[ex.n_arrays++] = PMF_ARR_BIAS;
         return pmf_comm_half_sweep(
             ctx, side, width, stats, true,
             [&] { return pmf_gauss_sgd_accumulate(ctx, side, stats, lr, sigma2, eta2, eta_bias2); },
-            [&] { return pmf_gauss_sgd_finalize(ctx, side, stats); });
+            [&] { return pmf_gauss_sgd_finalize(ctx, side, stats); }, ex);
     }
     const int saved = ctx->cur_chunk[side];
     ctx->cur_chunk[side] = -1;  // the one-call form always covers every row

@@ -14,6 +14,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpmf_hip.so")
+# The TEST build of the same sources (-DPMF_TEST_TRANSPORT): adds the `hostshm` rehearsal transport (ranks sharing
+# one GPU exchange through POSIX shared memory) and its entry point pmf_comm_init_hostshm.  Never loaded unless the
+# process asks for that transport (PMF_COMM_TRANSPORT=hostshm) or sets PMF_HIP_TEST_LIBRARY=1.
+TEST_LIB_PATH = os.path.join(_HERE, "libpmf_hip_test.so")
+TEST_ONLY_SIGNATURES = ("pmf_comm_init_hostshm",)
 
 F32, F64 = 0, 1
 USER, ITEM = 0, 1
@@ -25,6 +30,7 @@ KERNEL_NAMES = ("gamma_sweep", "gamma_final", "gauss_accum", "gauss_solve", "gau
 UNIQUE_ID_BYTES = 128
 TRANSPORT_RCCL, TRANSPORT_HOSTSHM = 0, 1
 OP_SUM, OP_MAX = 0, 1
+EXCHANGE = {"auto": 0, "allreduce": 1, "scatter_gather": 2}
 MAX_LABELS = 32
 
 
@@ -54,11 +60,6 @@ SIGNATURES = {
     "pmf_ctx_sgd_stats_width": (C.c_int, [_p, C.POINTER(C.c_int)]),
     "pmf_gauss_sgd_accumulate": (C.c_int, [_p, C.c_int, _p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "pmf_gauss_sgd_finalize": (C.c_int, [_p, C.c_int, _p]),
-    "pmf_graph_begin": (C.c_int, [_p]),
-    "pmf_graph_end": (C.c_int, [_p, C.POINTER(C.c_int)]),
-    "pmf_graph_abort": (C.c_int, [_p]),
-    "pmf_graph_launch": (C.c_int, [_p, C.c_int]),
-    "pmf_graph_destroy": (C.c_int, [_p, C.c_int]),
     "pmf_ctx_set_row_chunks": (C.c_int, [_p, C.c_int, C.c_int]),
     "pmf_ctx_chunk_rows": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmf_ctx_select_chunk": (C.c_int, [_p, C.c_int, C.c_int]),
@@ -91,7 +92,7 @@ SIGNATURES = {
     "pmf_prof_gather_ceiling": (C.c_int, [_p, C.c_int, C.c_int, _f64p]),
     "pmf_comm_unique_id": (C.c_int, [_p]),
     "pmf_comm_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
-    "pmf_comm_init_hostshm": (C.c_int, [_p, C.c_int, C.c_int, _p]),
+    "pmf_comm_set_exchange": (C.c_int, [_p, C.c_int]),
     "pmf_comm_attach": (C.c_int, [_p, _p]),
     "pmf_comm_destroy": (C.c_int, [_p]),
     "pmf_comm_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -99,6 +100,10 @@ SIGNATURES = {
     "pmf_comm_allreduce_host": (C.c_int, [_p, _f64p, C.c_int64, C.c_int]),
     "pmf_comm_gather_user_rows": (C.c_int, [_p, C.c_int, _i64p, _f64p]),
 }
+
+
+def wants_test_library():
+    return os.environ.get("PMF_HIP_TEST_LIBRARY") == "1" or os.environ.get("PMF_COMM_TRANSPORT") == "hostshm"
 
 _lib = None
 _loaded_before_torch = False
@@ -115,9 +120,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = TEST_LIB_PATH if wants_test_library() else LIB_PATH
+    if not os.path.exists(path):
         raise PmfLibraryError(
-            f"{LIB_PATH} not found: the HIP engine has not been built. Run "
+            f"{path} not found: the HIP engine has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` from the repository root. "
             "There is no CPU fallback.")
     # The CAVI engine does not use PyTorch.  One interaction has to be known, though: PyTorch-ROCm
@@ -138,16 +144,20 @@ def load():
         except Exception:
             pass
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as exc:  # missing libamdhip64 etc.
-        raise PmfLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
-    for name, (res, args) in SIGNATURES.items():
+        raise PmfLibraryError(f"cannot load {path}: {exc}") from exc
+    sigs = dict(SIGNATURES)
+    if path == TEST_LIB_PATH:
+        sigs["pmf_comm_init_hostshm"] = SIGNATURES["pmf_comm_init"]
+    for name, (res, args) in sigs.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as exc:
-            raise PmfLibraryError(f"{LIB_PATH} does not export {name}") from exc
+            raise PmfLibraryError(f"{path} does not export {name}") from exc
         fn.restype = res
         fn.argtypes = args
+    lib.pmf_path = path
     _lib = lib
     return lib
 

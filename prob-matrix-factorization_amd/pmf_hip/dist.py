@@ -72,9 +72,10 @@ class Comm:
 
     in_library = True
 
-    def __init__(self, rank, world, device, unique_id, transport="rccl"):
+    def __init__(self, rank, world, device, unique_id, transport="rccl", exchange=None):
         from .engine import Context
         self.rank, self.world, self.device, self.transport = int(rank), int(world), int(device), transport
+        self.exchange = exchange      # None = the library's default (PMF_COMM_EXCHANGE, else auto)
         self._anchor = Context(1, 1, 1, dtype="f32", device=self.device)
         try:
             self._anchor.comm_init(self.world, self.rank, unique_id, transport)
@@ -84,6 +85,8 @@ class Comm:
 
     def attach(self, ctx):
         ctx.comm_attach(self._anchor)
+        if self.exchange is not None:
+            ctx.comm_set_exchange(self.exchange)
         return ctx
 
     def all_reduce_host(self, values, op="sum"):
@@ -106,6 +109,22 @@ class Comm:
 
 
 _exchange_seq = 0
+_PROCESS_START = None
+
+
+def _process_start():
+    """Wall-clock time this process was started (the launcher spawns all ranks of a launch together)."""
+    global _PROCESS_START
+    if _PROCESS_START is None:
+        try:
+            with open("/proc/self/stat") as f:
+                ticks = float(f.read().rsplit(")", 1)[1].split()[19])      # starttime, clock ticks since boot
+            with open("/proc/uptime") as f:
+                up = float(f.read().split()[0])
+            _PROCESS_START = time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+        except Exception:
+            _PROCESS_START = time.time()
+    return _PROCESS_START
 
 
 def _id_file(tag):
@@ -113,44 +132,91 @@ def _id_file(tag):
     if explicit:
         return f"{explicit}.{tag}"
     base = os.environ.get("PMF_COMM_DIR", tempfile.gettempdir())
-    # all ranks of one launch are children of one launcher process (torch.distributed.run's agent,
-    # mp.spawn, a shell): its pid + the rendezvous port name the launch
-    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    # all ranks of one launch are children of one launcher process (torch.distributed.run's agent, mp.spawn, a
+    # shell): its pid, the rendezvous address / port and the launcher's run id name the launch.  That is NOT
+    # unique over time (a shell reuses its pid for the next launch, the run id defaults to "none"), so a file
+    # is only believed when it is younger than the reading process (see exchange_unique_id).
+    key = "_".join(str(os.environ.get(k, "0")) for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                                                         "TORCHELASTIC_RESTART_COUNT")) + f"_{os.getppid()}"
+    key = "".join(c if c.isalnum() or c in "._-" else "-" for c in key)
     return os.path.join(base, f"pmf_hip_uid_{key}.{tag}")
 
 
-def exchange_unique_id(rank, make_id, timeout=180.0):
-    """Rank 0 creates the 128-byte id and publishes it in a file (written whole, then renamed);
-    the other ranks wait for the file.  Called by every rank, the same number of times."""
+def exchange_unique_id(rank, make_id, timeout=None, world=None):
+    """Rank 0 creates the 128-byte id and publishes it in a file (any file left at that path by an earlier,
+    crashed launch is removed first; the new one is written whole, then renamed); the other ranks wait for a
+    file that is YOUNGER THAN THEIR OWN PROCESS -- a stale id from a previous launch of the same shell / port
+    is never accepted.  With `world`, every rank then acknowledges the id (`<path>.ack<rank>`) and waits until
+    all `world` acknowledgements exist, so a rank that never started ends in a TimeoutError here -- before
+    anybody sits in ncclCommInitRank, which has no deadline of its own.  Called by every rank, the same
+    number of times.  `timeout`: seconds (default PMF_COMM_INIT_TIMEOUT_S or 180)."""
     global _exchange_seq
+    if timeout is None:
+        timeout = float(os.environ.get("PMF_COMM_INIT_TIMEOUT_S", "180"))
     path = _id_file(_exchange_seq)
     _exchange_seq += 1
+    t0 = time.time()
     if rank == 0:
+        for stale in [path] + ([f"{path}.ack{r}" for r in range(world)] if world else []):
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
         uid = make_id()
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)
-        return uid, path
-    t0 = time.time()
-    while True:
-        try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == UNIQUE_ID_BYTES:
-                return uid, path
-        except FileNotFoundError:
-            pass
-        if time.time() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
-        time.sleep(0.01)
+    else:
+        born = _process_start() - 2.0        # (clock granularity; the launcher starts the ranks within milliseconds)
+        while True:
+            try:
+                if os.stat(path).st_mtime >= born:
+                    with open(path, "rb") as f:
+                        uid = f.read()
+                    if len(uid) == UNIQUE_ID_BYTES:
+                        break
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"rank {rank}: no fresh communicator id at {path} after {timeout:.0f} s "
+                                   "(rank 0 never published one)")
+            time.sleep(0.01)
+    if world:
+        ack = f"{path}.ack{rank}"
+        with open(ack, "wb") as f:
+            f.write(uid)                      # the id this rank is about to use
+        missing = list(range(world))
+        while missing:
+            still = []
+            for r in missing:
+                try:
+                    with open(f"{path}.ack{r}", "rb") as f:
+                        seen = f.read()
+                    if len(seen) < UNIQUE_ID_BYTES:
+                        still.append(r)       # (being written)
+                    elif seen != uid:
+                        if os.stat(f"{path}.ack{r}").st_mtime >= _process_start() - 2.0:
+                            raise RuntimeError(f"rank {rank}: rank {r} acknowledged a different communicator id at {path}")
+                        still.append(r)       # a leftover of an earlier launch: rank r has not written its own yet
+                except FileNotFoundError:
+                    still.append(r)
+            missing = still
+            if missing and time.time() - t0 > timeout:
+                raise TimeoutError(f"rank {rank}: ranks {missing} of {world} never acknowledged the communicator id at "
+                                   f"{path} within {timeout:.0f} s -- not starting the collective initialisation")
+            if missing:
+                time.sleep(0.01)
+    return uid, path
 
 
-def init_from_env(device=None, transport=None):
+def init_from_env(device=None, transport=None, exchange=None):
     """The communicator of a launcher-started process, or None for a single process.
 
     Reads RANK, WORLD_SIZE, LOCAL_RANK (the GPU of this rank unless `device` is given).  `transport`:
-    'rccl' (default; PMF_COMM_TRANSPORT overrides) or 'hostshm' for ranks that share one GPU."""
+    'rccl' (default; PMF_COMM_TRANSPORT overrides) or 'hostshm' for ranks that share one GPU (test build of
+    the library only).  `exchange`: 'auto' | 'allreduce' | 'scatter_gather' for the contexts attached later
+    (default: the library's, i.e. PMF_COMM_EXCHANGE or auto)."""
     from .engine import Context
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
@@ -159,12 +225,14 @@ def init_from_env(device=None, transport=None):
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
     transport = transport or os.environ.get("PMF_COMM_TRANSPORT", "rccl")
-    uid, path = exchange_unique_id(rank, Context.comm_unique_id)
-    comm = Comm(rank, world, device, uid, transport)
-    comm.barrier()            # every rank has read the file
-    if rank == 0:
+    if transport == "hostshm":
+        os.environ["PMF_COMM_TRANSPORT"] = "hostshm"      # selects the test build of the library (pmf_hip.load)
+    uid, path = exchange_unique_id(rank, Context.comm_unique_id, world=world)
+    comm = Comm(rank, world, device, uid, transport, exchange=exchange)
+    comm.barrier()            # every rank is inside the communicator
+    for leftover in ([path] if rank == 0 else []) + [f"{path}.ack{rank}"]:
         try:
-            os.remove(path)
+            os.remove(leftover)
         except OSError:
             pass
     return comm

@@ -10,8 +10,8 @@ import ctypes as C
 
 import numpy as np
 
-from . import (ARR_COV, F32, F64, ITEM, KERNEL_NAMES, MAX_LABELS, OP_MAX, OP_SUM, UNIQUE_ID_BYTES, USER, PmfError,
-               as_f64, as_i32, check, load, ptr)
+from . import (ARR_COV, EXCHANGE, F32, F64, ITEM, KERNEL_NAMES, MAX_LABELS, OP_MAX, OP_SUM, TEST_LIB_PATH, UNIQUE_ID_BYTES,
+               USER, PmfError, PmfLibraryError, as_f64, as_i32, check, load, ptr)
 
 
 class Context:
@@ -30,12 +30,6 @@ class Context:
         self.cov_stride = k.value
         self.nnz = 0
         self.n_chunks = {USER: 1, ITEM: 1}
-
-    # ---- HIP graphs -------------------------------------------------------
-    def capture(self):
-        """`with ctx.capture() as g: <sweep calls>` records the calls instead of running them;
-        `g.launch()` replays them.  Run the same calls once normally first."""
-        return _Capture(self)
 
     # ---- row chunks (multi-GPU pipelining of a half-sweep) --------------
     def set_row_chunks(self, side, n_chunks):
@@ -63,11 +57,24 @@ class Context:
         return buf.raw
 
     def comm_init(self, nranks, rank, unique_id, transport="rccl"):
-        """Collective.  transport 'rccl' (one rank per GPU) or 'hostshm' (rehearsal: ranks share one GPU)."""
+        """Collective.  transport 'rccl' (one rank per GPU), or 'hostshm' -- the rehearsal transport of the TEST build
+        of the library (ranks share one GPU), loaded only when the process asked for it (`pmf_hip.wants_test_library`)."""
         if len(unique_id) != UNIQUE_ID_BYTES:
             raise ValueError(f"unique_id must be {UNIQUE_ID_BYTES} bytes")
-        fn = {"rccl": self._lib.pmf_comm_init, "hostshm": self._lib.pmf_comm_init_hostshm}[transport]
+        if transport == "hostshm":
+            if not hasattr(self._lib, "pmf_comm_init_hostshm") or self._lib.pmf_path != TEST_LIB_PATH:
+                raise PmfLibraryError("the hostshm transport exists in the test build of the library only: set "
+                                      "PMF_COMM_TRANSPORT=hostshm (or PMF_HIP_TEST_LIBRARY=1) before the first engine call")
+            fn = self._lib.pmf_comm_init_hostshm
+        else:
+            fn = {"rccl": self._lib.pmf_comm_init}[transport]
         check(fn(self._h, int(nranks), int(rank), C.c_char_p(bytes(unique_id))), f"pmf_comm_init[{transport}]")
+
+    def comm_set_exchange(self, mode):
+        """'auto' (default), 'allreduce' or 'scatter_gather': how an ITEM half-sweep's statistics travel (the same
+        on every rank) -- all-reduce + every rank finalises every item, or reduce-scatter -> finalise 1/N of the
+        items -> all-gather of the finalised rows."""
+        check(self._lib.pmf_comm_set_exchange(self._h, EXCHANGE[mode]), "pmf_comm_set_exchange")
 
     def comm_attach(self, owner):
         check(self._lib.pmf_comm_attach(self._h, owner._h), "pmf_comm_attach")
@@ -341,27 +348,6 @@ class Context:
             check(self._lib.pmf_prof_get(self._h, k, C.byref(ms), C.byref(n)), "pmf_prof_get")
             out[name] = (ms.value, n.value)
         return out
-
-
-class _Capture:
-    def __init__(self, ctx):
-        self._ctx, self.graph_id = ctx, None
-
-    def __enter__(self):
-        check(self._ctx._lib.pmf_graph_begin(self._ctx._h), "pmf_graph_begin")
-        return self
-
-    def __exit__(self, exc_type, exc, tb):
-        if exc_type is not None:
-            self._ctx._lib.pmf_graph_abort(self._ctx._h)
-            return False
-        gid = C.c_int(-1)
-        check(self._ctx._lib.pmf_graph_end(self._ctx._h, C.byref(gid)), "pmf_graph_end")
-        self.graph_id = gid.value
-        return False
-
-    def launch(self):
-        check(self._ctx._lib.pmf_graph_launch(self._ctx._h, self.graph_id), "pmf_graph_launch")
 
 
 __all__ = ["Context", "PmfError", "USER", "ITEM"]

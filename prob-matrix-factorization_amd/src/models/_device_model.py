@@ -68,8 +68,6 @@ class DeviceModel:
         self._device = engine_device(device)
         self._ctx = None
         self._shard_ctx = None
-        self._graph = None
-        self._graph_calls = 0
         # structured per-iteration record next to the reference's stdout lines
         self.history_ = {"val_rmse": [], "val_macro_mae": [], "iterations": 0, "stopped_early": False,
                          "seconds": []}
@@ -166,7 +164,6 @@ class DeviceModel:
             self._ctx.set_row_chunks(pmf_hip.ITEM, pdist.default_item_chunks(
                 self._comm.world, pdist.item_message_bytes(self._ctx, self._gaussian)))
         self._ctx.set_ratings(u, i, x)
-        self._graph, self._graph_calls = None, 0
         import time
         self._t_last = time.perf_counter()
         for key in ("val_rmse", "val_macro_mae", "seconds"):
@@ -174,25 +171,9 @@ class DeviceModel:
         self.history_["iterations"], self.history_["stopped_early"] = 0, False
         return self._ctx
 
-    # ---- one iteration: eager, then captured once, then replayed -------------
     def _run_iteration(self, issue):
-        """`issue()` makes the sweep calls of one iteration.  With PMF_HIP_GRAPH=1 the calls of the
-        second iteration are captured into a HIP graph that is replayed from the third on (the first
-        runs normally: it allocates the lazily created arrays and scratch buffers).  Off by default:
-        measured at the reference's sizes the iteration is bound by the kernels' own dependent gather
-        rounds, not by launches (BASELINE config C1: 32.4 us issued, 36.1 us replayed), and a capture
-        must not overlap other host threads' default-stream copies (the tuner's concurrent trials)."""
-        if self._comm is not None or os.environ.get("PMF_HIP_GRAPH", "0") != "1":
-            return issue()
-        n = self._graph_calls
-        self._graph_calls += 1
-        if n == 0:
-            return issue()
-        if n == 1:
-            with self._ctx.capture() as graph:
-                issue()
-            self._graph = graph
-        self._graph.launch()
+        """`issue()` makes the sweep calls of one iteration (asynchronous launches on the context's stream)."""
+        return issue()
 
     # ---- multi-GPU helpers --------------------------------------------------
     def _mine(self, user_array):

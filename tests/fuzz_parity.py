@@ -175,7 +175,7 @@ def sweep(n_trials, seed, quiet=False):
     for t in range(n_trials):
         kind = str(rng.choice(list(KEYS)))
         dtype = str(rng.choice(["f64", "f64", "f32"]))
-        K = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 24, 31, 32, 33, 40, 48, 49, 56, 57, 64, 65, 72, 80, 96, 100, 128, 130]))
+        K = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 24, 31, 32, 33, 40, 48, 49, 56, 57, 64, 65, 72, 79, 80, 81, 88, 95, 96, 100, 128, 130]))
         if (kind.startswith("gauss") or kind == "sgd") and K > 64 and rng.random() < 0.5:
             K = int(rng.integers(1, 64))              # keep most Gaussian cases cheap for the CPU oracle
         shape, u, i, x, val = problem(rng)
@@ -230,6 +230,7 @@ def sweep_three_stage(n_trials, seed, quiet=False):
                     with pmf_hip.Context(U, I, K, dtype=dtype) as ctx:
                         if with_comm:
                             comm.attach(ctx)
+                            ctx.comm_set_exchange(["allreduce", "scatter_gather"][t % 2])   # ncclAllReduce | ncclReduceScatter + ncclAllGather
                             ctx.set_row_chunks(ITEM, n_chunks)
                         if kind in ("poisson", "hpf"):
                             ctx.set_ratings(u, i, x + 1.0)
@@ -280,48 +281,6 @@ def sweep_three_stage(n_trials, seed, quiet=False):
     finally:
         comm.close()
     return bad, worst
-
-
-def sweep_graph(n_trials, seed):
-    """PMF_HIP_GRAPH=1 (second iteration captured into a HIP graph, replayed from the third on) against the
-    plain issue order on random problems: every array bit-identical.  Returns the number of failures."""
-    import fuzz_sharded
-    rng = np.random.default_rng(seed)
-    bad = 0
-    for t in range(n_trials):
-        kind = str(rng.choice(["hpf", "poisson", "gauss_bias", "gauss"]))
-        K = int(rng.choice([1, 5, 16, 30, 40, 64, 72, 128]))
-        shape, u, i, x, (vu, vi, vx) = problem(rng)
-        seed_t, iters = int(rng.integers(0, 1000)), int(rng.integers(3, 7))
-        train = pd.DataFrame({"u": u, "i": i, "rating": x})
-        val = pd.DataFrame({"u": vu, "i": vi, "rating": vx}) if rng.random() < 0.7 else None
-        gm = float(train["rating"].mean())
-        states = []
-        try:
-            for flag in ("0", "1"):
-                os.environ["PMF_HIP_GRAPH"] = flag
-                m = fuzz_sharded.build(kind, K, seed_t, iters)
-                if val is None:
-                    if kind.startswith("gauss"):
-                        m.fit(train.assign(rating=train["rating"] - gm), global_mean=gm)
-                    else:
-                        m.fit(train.assign(rating=train["rating"] + 1.0))
-                else:
-                    fuzz_sharded.fit(kind, m, train, val, gm)
-                states.append([np.asarray(getattr(m, k)) for k in fuzz_sharded.KEYS[kind]] +
-                              [np.asarray(m.history_["val_rmse"])])
-                m.close()
-            same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(*states))
-            msg = "" if same else "arrays differ"
-        except Exception as e:     # noqa: BLE001
-            same, msg = False, f"{type(e).__name__}: {e}"
-        finally:
-            os.environ.pop("PMF_HIP_GRAPH", None)
-        if not same:
-            bad += 1
-            print(f"FAIL graph trial {t}: {kind} K={K} shape={shape} U={u.max() + 1} I={i.max() + 1} N={len(u)} "
-                  f"iters={iters} val={val is not None}: {msg}", flush=True)
-    return bad
 
 
 def sweep_index(n_trials, seed):
@@ -449,8 +408,6 @@ if __name__ == "__main__":
     print(f"{n} trials, {failures} failures")
     f3, w3 = sweep_three_stage(n // 2, 7)
     print(f"three-stage path vs fused sweeps: {n // 2} trials, {f3} failures, worst f32 deviation {w3:.2e}")
-    fg = sweep_graph(n // 4, 8)
-    print(f"graph replay vs issued iterations: {n // 4} trials, {fg} failures")
     fi = sweep_index(n // 10, 9)
     print(f"device index build vs host build: {n // 10} trials, {fi} failures")
-    sys.exit(1 if failures or f3 or fg or fi else 0)
+    sys.exit(1 if failures or f3 or fi else 0)

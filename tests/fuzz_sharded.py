@@ -59,12 +59,13 @@ def worker(rank, world, port, n_trials, seed, out_path):
         pre = bool(rng.integers(0, 2))
         explicit = bool(rng.integers(0, 2))
         os.environ["PMF_DIST_CHUNKS"] = str(int(rng.integers(1, 5)))
+        comm.exchange = [None, "allreduce", "scatter_gather"][int(rng.integers(0, 3))]   # applied when the model attaches its context
         train = pd.DataFrame({"u": u, "i": i, "rating": x})
         val = pd.DataFrame({"u": vu, "i": vi, "rating": vx})
         gm = float(train["rating"].mean())
         mine_t, mine_v = train, val
         tag = f"trial {t}: {kind} K={K} shape={shape} U={int(u.max()) + 1} I={int(i.max()) + 1} N={len(u)} pre={pre} explicit={explicit} " \
-              f"chunks={os.environ['PMF_DIST_CHUNKS']} iters={iters}"
+              f"chunks={os.environ['PMF_DIST_CHUNKS']} exchange={comm.exchange} iters={iters}"
         try:
             arg = False
             if pre:      # this rank is handed only its own rows (global ids)

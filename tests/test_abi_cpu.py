@@ -21,17 +21,32 @@ def built():
     return pmf_hip
 
 
-def _declared():
+def _declared(test_build=False):
+    """functions the header declares for the product build (`test_build`: those inside #ifdef PMF_TEST_TRANSPORT only)"""
     text = open(os.path.join(ROOT, "include", "pmf_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"\b(pmf_[a-z0-9_]+)\s*\(", text))
+    guarded = "".join(re.findall(r"#ifdef PMF_TEST_TRANSPORT(.*?)#endif", text, flags=re.S))
+    product = re.sub(r"#ifdef PMF_TEST_TRANSPORT.*?#endif", "", text, flags=re.S)
+    return set(re.findall(r"\b(pmf_[a-z0-9_]+)\s*\(", guarded if test_build else product))
+
+
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if " T pmf_" in line}
 
 
 def test_header_and_binding_list_the_same_functions(built):
     assert _declared() == set(built.SIGNATURES)
+    assert _declared(test_build=True) == set(built.TEST_ONLY_SIGNATURES)
 
 
-def test_library_exports_every_declared_symbol(built):
+def test_library_exports_exactly_the_declared_symbols(built):
+    """The product library exports the header's product functions and nothing else -- in particular no test
+    transport (`hostshm` lives in libpmf_hip_test.so only); the test build adds exactly the guarded ones."""
+    assert _exported(built.LIB_PATH) == _declared()
+    assert _exported(built.TEST_LIB_PATH) == _declared() | _declared(test_build=True)
+    blob = open(built.LIB_PATH, "rb").read()
+    assert b"shm_open" not in blob and b"hostshm transport:" not in blob
     lib = ctypes.CDLL(built.LIB_PATH)
     for name in _declared():
         assert hasattr(lib, name), name

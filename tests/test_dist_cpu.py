@@ -346,3 +346,62 @@ def test_presharded_contract_over_gloo(tmp_path):
         stray, bad = open(os.path.join(tmp_path, f"contract{rank}.txt")).read().splitlines()
         assert "1 validation row(s) were given to a rank that does not own" in stray
         assert "training row(s) lie outside their rank's user range" in bad
+
+
+# ---- the communicator-id rendezvous (pmf_hip/dist.py:exchange_unique_id) -------------------------------
+_RDV = r'''
+import os, sys, time
+sys.path[:0] = [{pkg!r}]
+from pmf_hip import dist
+rank, world, timeout = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+try:
+    uid, path = dist.exchange_unique_id(rank, lambda: bytes([65 + rank]) * 128, timeout=timeout, world=world)
+    print("OK", uid[:1].decode(), flush=True)
+except TimeoutError as e:
+    print("TIMEOUT", e, flush=True)
+    sys.exit(3)
+'''
+
+
+def _rdv(rank, world, timeout, id_file):
+    import subprocess
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prob-matrix-factorization_amd")
+    env = dict(os.environ, PMF_COMM_ID_FILE=id_file)
+    return subprocess.Popen([sys.executable, "-c", _RDV.format(pkg=pkg), str(rank), str(world), str(timeout)], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def test_id_rendezvous_ignores_a_stale_file_and_hands_every_rank_the_new_id(tmp_path):
+    """A crashed launch left an id file (and acknowledgements) at the path the next launch of the same shell / port
+    uses: the new ranks must end with rank 0's NEW id, never with the leftover."""
+    import time
+    base = str(tmp_path / "uid")
+    old = time.time() - 3600
+    for name, content in ((base + ".0", b"Z" * 128), (base + ".0.ack1", b"Z" * 128)):
+        with open(name, "wb") as f:
+            f.write(content)
+        os.utime(name, (old, old))
+    late = _rdv(1, 2, 20, base)          # rank 1 arrives first and finds only the stale file
+    time.sleep(1.0)
+    first = _rdv(0, 2, 20, base)
+    out0, out1 = first.communicate(timeout=60)[0], late.communicate(timeout=60)[0]
+    assert first.returncode == 0 and late.returncode == 0, (out0, out1)
+    assert out0.strip() == "OK A" and out1.strip() == "OK A", (out0, out1)
+
+
+def test_id_rendezvous_has_a_deadline_for_a_peer_that_never_starts(tmp_path):
+    """Rank 0 of a 2-rank launch whose peer never starts: a TimeoutError before anybody calls ncclCommInitRank
+    (which has no deadline of its own), not a hang; likewise a rank 1 that only ever sees a stale id."""
+    import time
+    base = str(tmp_path / "uid")
+    alone = _rdv(0, 2, 1.5, base)
+    out = alone.communicate(timeout=60)[0]
+    assert alone.returncode == 3 and "never acknowledged" in out and "[1]" in out, out
+    stale = str(tmp_path / "uid2")
+    with open(stale + ".0", "wb") as f:
+        f.write(b"Z" * 128)
+    old = time.time() - 3600
+    os.utime(stale + ".0", (old, old))
+    orphan = _rdv(1, 2, 1.5, stale)
+    out = orphan.communicate(timeout=60)[0]
+    assert orphan.returncode == 3 and "no fresh communicator id" in out, out

@@ -127,7 +127,7 @@ def _oracle_vs_device(K, dtype, bias, U=1500, I=300, N=40000, iters=2, env=None,
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 2e-4)])
-@pytest.mark.parametrize("K", [1, 5, 8, 16, 30, 32, 45, 48, 50, 64, 72, 100, 128])
+@pytest.mark.parametrize("K", [1, 5, 8, 16, 30, 32, 45, 48, 50, 64, 72, 88, 100, 128])
 def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
     """Direct C-ABI calls on a skewed problem: split rows, empty rows, every
     solver width (register kernels up to 64, LDS kernel above)."""
@@ -140,16 +140,27 @@ def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
         assert np.max(np.abs(got[key] - st[key]) / scale) <= tol, key
 
 
-@pytest.mark.parametrize("K", [5, 16, 20, 30, 32, 33, 40, 45, 48, 49, 50, 52, 64, 70, 100, 120, 128])
+@pytest.mark.parametrize("K", [5, 16, 20, 30, 32, 33, 40, 45, 48, 49, 50, 52, 64, 70, 79, 81, 88, 95, 100, 120, 128])
 def test_mfma_kernel_matches_generic_kernel(K, monkeypatch):
     """The fp32 fast paths (K <= 64: one wavefront per task; 64 < K <= 128: two) (MFMA outer products, fused solve) against the
-    generic accumulate kernel + standalone solve on the same inputs."""
+    generic accumulate kernel + standalone solve on the same inputs.  Above 64 also the un-fused launches
+    (PMF_GAUSS_UNFUSED: accumulate-only kernel + `gauss_solve_pair_kernel`), i.e. both homes of the two-wave solve: K = 79
+    is the RW = 40 row split's odd tail; 81 / 88 / 95 the RW = 48 split with a PARTIAL wave-1 phase (np1 < NP), an odd-K
+    tail step and the un-rotation of wave 1's registers in the epilogue (only K = 96, where wave 1 runs
+    all its pivot pairs, was covered)."""
     small = dict(N=20000) if K <= 64 else dict(N=7000, I=50, U=800)
     fast, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, with_oracle=False, **small)
+    unfused = None
+    if K > 64:
+        monkeypatch.setenv("PMF_GAUSS_UNFUSED", "1")
+        unfused, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, with_oracle=False, **small)
+        monkeypatch.delenv("PMF_GAUSS_UNFUSED")
     monkeypatch.setenv("PMF_GAUSS_GENERIC", "1")
     slow, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, with_oracle=False, **small)
     for key in fast:
         assert max_abs(fast[key], slow[key]) <= 3e-5, key
+        if unfused is not None:
+            assert max_abs(unfused[key], slow[key]) <= 3e-5, (key, "unfused")
 
 
 def test_empty_rows_keep_initial_state():

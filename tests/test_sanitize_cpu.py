@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAN_DRIVER = r'''
 import ctypes as C, re, sys
 lib = C.CDLL(sys.argv[1])
-text = re.sub(r"/\*.*?\*/", "", open(sys.argv[2]).read(), flags=re.S)
+text = re.sub(r"/\*.*?\*/", "", open(sys.argv[2]).read(), flags=re.S)   # (incl. the PMF_TEST_TRANSPORT prototypes: this build has them)
 protos = re.findall(r"\b(?:int|const char \*)\s*(pmf_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text)
 assert len(protos) > 50, len(protos)
 lib.pmf_last_error.restype = C.c_char_p
@@ -77,6 +77,7 @@ def test_host_side_under_address_and_ub_sanitizers(tmp_path):
         objs.append(o)
         procs.append(subprocess.Popen(
             [hipcc, "-O1", "-g", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-result",
+             "-DPMF_TEST_TRANSPORT",     # the hostshm rehearsal transport is host code: it is sanitised with the rest
              "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
              "-Xarch_host", "-fno-sanitize-recover=undefined", "-Xarch_host", "-fno-omit-frame-pointer",
              "-I", os.path.join(ROOT, "include"), "-I", g.CSRC, "-c", os.path.join(g.CSRC, src), "-o", o],

@@ -79,14 +79,16 @@ def _fit(kind, model, train, val, gm=None):
     return model.predict(val["u"].to_numpy(), val["i"].to_numpy())
 
 
-def _worker(rank, world, port, kind, out_dir):
-    """One rank of a sharded fit: a fresh interpreter (spawn) that must get by without torch."""
+def _worker(rank, world, port, kind, out_dir, exchange=None):
+    """One rank of a sharded fit: a fresh interpreter (spawn) that must get by without torch.
+    `exchange`: None = the library's choice (reduce-scatter -> finalize owned rows -> all-gather for the Gaussian
+    factor sweep, all-reduce for the rest), or 'allreduce' / 'scatter_gather' for every item half-sweep."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", PMF_COMM_TRANSPORT="hostshm")
     os.environ["PMF_DIST_CHUNKS"] = "3"   # the messages here are too small for the default to pipeline
     from pmf_hip import dist as pdist
-    comm = pdist.init_from_env(device=0)
+    comm = pdist.init_from_env(device=0, exchange=exchange)
     assert comm.world == world and comm.rank == rank and comm.transport == "hostshm"
     train, val = _data()
     pre = kind.endswith("_pre")
@@ -119,10 +121,10 @@ def _worker(rank, world, port, kind, out_dir):
     comm.close()
 
 
-def _spawn(kind, out_dir, world=2):
+def _spawn(kind, out_dir, world=2, exchange=None):
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, out_dir)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, out_dir, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -135,13 +137,17 @@ def _spawn(kind, out_dir, world=2):
     assert [p.exitcode for p in procs] == [0] * world
 
 
-@pytest.mark.parametrize("kind", ["hpf", "poisson", "gauss", "hpf_pre", "gauss_pre"])
-def test_two_rank_fit_matches_single_process(kind, tmp_path):
-    """`*_pre`: the presharded form -- every rank is given only its own training / validation rows."""
+@pytest.mark.parametrize("kind,exchange", [("hpf", None), ("poisson", None), ("gauss", None), ("hpf_pre", None),
+                                           ("gauss_pre", None), ("hpf", "scatter_gather"), ("poisson", "scatter_gather"),
+                                           ("gauss", "allreduce")])
+def test_two_rank_fit_matches_single_process(kind, exchange, tmp_path):
+    """`*_pre`: the presharded form -- every rank is given only its own training / validation rows.  `exchange`:
+    None = the library's choice per sweep (Gaussian factor sweep: reduce-scatter -> each rank solves its half of
+    every chunk's items -> all-gather; the others: all-reduce), or one exchange forced on every item half-sweep."""
     train, val = _data()
     model, keys = _build(kind[:-4] if kind.endswith("_pre") else kind)
     pred = _fit(kind[:-4] if kind.endswith("_pre") else kind, model, train, val)
-    _spawn(kind, str(tmp_path))
+    _spawn(kind, str(tmp_path), exchange=exchange)
     kind = kind[:-4] if kind.endswith("_pre") else kind
     for rank in range(2):
         d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
@@ -155,15 +161,17 @@ def test_two_rank_fit_matches_single_process(kind, tmp_path):
                                        rtol=1e-8, atol=1e-11)
 
 
-@pytest.mark.parametrize("kind,world", [("hpf", 3), ("gauss_pre", 4)])
-def test_more_ranks_than_two_match_single_process(kind, world, tmp_path):
+@pytest.mark.parametrize("kind,world,exchange", [("hpf", 3, None), ("gauss_pre", 4, None), ("gauss", 3, None),
+                                                 ("hpf", 3, "scatter_gather")])
+def test_more_ranks_than_two_match_single_process(kind, world, exchange, tmp_path):
     """Nothing in the path is specific to two ranks: 3 and 4 ranks on the one GPU (hostshm), full-frame and
-    presharded, against the single-process fit."""
+    presharded, against the single-process fit.  (400 items in 3 chunks over 3 ranks: sub-ranges of 44 rows and
+    one row per chunk left over for the all-reduce of the scatter-gather exchange.)"""
     base = kind[:-4] if kind.endswith("_pre") else kind
     train, val = _data()
     model, keys = _build(base)
     pred = _fit(base, model, train, val)
-    _spawn(kind, str(tmp_path), world=world)
+    _spawn(kind, str(tmp_path), world=world, exchange=exchange)
     for rank in range(world):
         d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         assert int(d["iters"]) == model.history_["iterations"]
@@ -173,14 +181,15 @@ def test_more_ranks_than_two_match_single_process(kind, world, tmp_path):
         np.testing.assert_allclose(d["pred"], pred, rtol=1e-9, atol=1e-11)
 
 
-def test_two_rank_gradient_mode_fit_is_consistent(tmp_path):
+@pytest.mark.parametrize("exchange", [None, "scatter_gather"])
+def test_two_rank_gradient_mode_fit_is_consistent(exchange, tmp_path):
     """The gradient mode averages the displacements of an item's pieces, so a sharded fit is a
     different (equally valid) trajectory than the single-process one: the ranks must agree with
     each other exactly and follow the same validation curve within 3 %."""
     train, val = _data()
     model, keys = _build("sgd")
     _fit("sgd", model, train, val)
-    _spawn("sgd", str(tmp_path))
+    _spawn("sgd", str(tmp_path), exchange=exchange)
     d0, d1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
     for k in keys + ("pred", "val_rmse"):
         assert np.array_equal(d0[k], d1[k]), k
@@ -199,12 +208,16 @@ def _bench(extra, world=2):
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("workload,chunks", [("gaussian_mf", 4), ("hpf_cavi", 4), ("gaussian_mf", 1), ("gaussian_mf_sgd", 4)])
-def test_bench_two_rank_rehearsal_strong_scales_the_one_matrix(workload, chunks):
+@pytest.mark.parametrize("workload,chunks,exchange", [("gaussian_mf", 4, "auto"), ("hpf_cavi", 4, "auto"), ("gaussian_mf", 1, "auto"),
+                                                      ("gaussian_mf_sgd", 4, "auto"), ("gaussian_mf", 4, "allreduce"),
+                                                      ("hpf_cavi", 4, "scatter_gather")])
+def test_bench_two_rank_rehearsal_strong_scales_the_one_matrix(workload, chunks, exchange):
     """bench.py launched as the driver launches it (torch.distributed.run, 2 ranks; the hostshm transport
     and one shared GPU stand in for RCCL over two): the ONE matrix is sharded (strong scaling), the
-    replicated item state ends bit-identical on both ranks, and the ranks never import torch."""
-    res = _bench(["--workload", workload, "--chunks", str(chunks)])
+    replicated item state ends bit-identical on both ranks -- under either exchange of the item statistics --
+    and the ranks never import torch."""
+    res = _bench(["--workload", workload, "--chunks", str(chunks), "--exchange", exchange])
+    assert res["config"]["exchange"] == exchange
     assert res["n_gpus"] == 2 and res["scaling"] == "strong"
     assert res["config"]["ratings_total"] == 5_000_000 and res["config"]["n_users"] == 100_000
     assert 0 < res["config"]["ratings_on_rank0"] < 5_000_000
@@ -237,8 +250,9 @@ def test_single_gpu_bench_line_is_complete_and_torch_free():
 def test_pipelined_item_sweep_over_real_rccl_single_rank():
     """The one-GPU box cannot hold two RCCL ranks, but it can run the real thing with one: a context with
     a one-rank RCCL communicator takes the in-library three-stage path (accumulate, ncclAllReduce of each
-    chunk's slice on the collective stream, event-ordered finalize) and must give bit for bit what the
-    explicit accumulate / finalize calls give on a caller-owned buffer without any collective."""
+    chunk's slice on the collective stream -- or ncclReduceScatter, finalize of the owned rows, ncclAllGather of the
+    finalised state --, event-ordered finalize) and must give bit for bit what the explicit accumulate / finalize
+    calls give on a caller-owned buffer without any collective."""
     import torch
     import pmf_hip
     from pmf_hip import ARR_BIAS, ARR_COV, ARR_FACTOR, ITEM, USER, TRANSPORT_RCCL, dist as pdist
@@ -253,10 +267,11 @@ def test_pipelined_item_sweep_over_real_rccl_single_rank():
         rng = np.random.default_rng(0)
         m_u, m_i = 0.1 * rng.standard_normal((U, K)), 0.1 * rng.standard_normal((I, K))
         out = []
-        for with_comm in (True, False):
+        for with_comm in ("allreduce", "scatter_gather", False):   # ncclAllReduce | ncclReduceScatter + ncclAllGather | no collective
             ctx = pmf_hip.Context(U, I, K)
             if with_comm:
                 comm.attach(ctx)
+                ctx.comm_set_exchange(with_comm)
                 assert ctx.comm_info() == (1, 0, TRANSPORT_RCCL)
             ctx.set_row_chunks(ITEM, 4)
             ctx.set_ratings(u, i, r - r.mean())
@@ -303,8 +318,9 @@ def test_pipelined_item_sweep_over_real_rccl_single_rank():
                 with pytest.raises(pmf_hip.PmfError):
                     ctx.gamma_ext_sweep(ITEM, 0.3, 0.3)
             ctx.close()
-        for a, b in zip(*out):
-            assert np.array_equal(a, b)
+        for other in out[:2]:
+            for a, b in zip(other, out[2]):
+                assert np.array_equal(a, b)
     finally:
         comm.close()
 

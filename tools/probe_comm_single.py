@@ -1,7 +1,12 @@
 """Per-GPU cost of the multi-GPU code path with the REAL RCCL calls in it, on one GPU: a C2 / C3-sized context with a
-one-rank RCCL communicator attached (ITEM half-sweeps = accumulate -> ncclAllReduce per chunk on the collective
+one-rank RCCL communicator attached (ITEM half-sweeps = accumulate -> collective per chunk on the collective
 stream -> finalize) against the same context without one (fused sweeps).
-    python tools/probe_comm_single.py [gauss|hpf] [chunks ...]"""
+    python tools/probe_comm_single.py [gauss|hpf|gauss_k128] [chunks ...]
+`gauss_k128` = BASELINE config C4's per-GPU shard (K = 128, 1.25M x 1M, 62.5M ratings): the path a C4 rank really runs.
+Three forms are timed: fused (no communicator); item side in three stages (accumulate-only kernel, collective, row solves
+on the finalize stream) with the user side fused; the same with the user side un-fused too (PMF_GAUSS_UNFUSED:
+accumulate-only + a separate solve launch on the compute stream).  Both exchanges (all-reduce; reduce-scatter ->
+finalize -> all-gather, which with one rank finalises everything too) are run."""
 import json
 import os
 import sys
@@ -21,15 +26,24 @@ def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "gauss"
     chunk_list = [int(a) for a in sys.argv[2:]] or [1, 4, 8]
     U, I, N, K = 1_000_000, 100_000, 50_000_000, 64
+    if kind == "gauss_k128":
+        U, I, N, K = 1_250_000, 1_000_000, 62_500_000, 128
     u, i, r = synth_ratings(U, I, N, seed=BASE_SEED)
     comm = pdist.Comm(0, 1, 0, Context.comm_unique_id(), "rccl")
     rng = np.random.default_rng(1)
-    for chunks in [0] + chunk_list:     # 0 = no communicator (fused sweeps)
+    forms = [(0, "auto", False)] + [(c, ex, False) for c in chunk_list for ex in ("allreduce", "scatter_gather")]
+    if kind == "gauss_k128":
+        forms += [(0, "auto", True)] + [(c, "allreduce", True) for c in chunk_list]
+    for chunks, exchange, unfused in forms:     # chunks 0 = no communicator (fused sweeps)
+        os.environ.pop("PMF_GAUSS_UNFUSED", None)
+        if unfused:
+            os.environ["PMF_GAUSS_UNFUSED"] = "1"       # read when the context is created
         ctx = pmf_hip.Context(U, I, K)
         if chunks:
             comm.attach(ctx)
+            ctx.comm_set_exchange(exchange)
             ctx.set_row_chunks(ITEM, chunks)
-        if kind == "gauss":
+        if kind.startswith("gauss"):
             ctx.set_ratings(u, i, r - r.mean())
             ctx.set_array(USER, ARR_FACTOR, 0.1 * rng.standard_normal((U, K)))
             ctx.set_array(ITEM, ARR_FACTOR, 0.1 * rng.standard_normal((I, K)))
@@ -47,18 +61,20 @@ def main():
 
             def step():
                 pdist.gamma_iteration(ctx, comm if chunks else None, None, up, ip)
-        for _ in range(2):
+        reps = 3 if kind == "gauss_k128" else 5
+        for _ in range(1 if kind == "gauss_k128" else 2):
             step()
         ctx.sync()
         ctx.prof_enable(True); ctx.prof_reset()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(reps):
             step()
         ctx.sync()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
-        prof = {k: round(v[0] / 5, 3) for k, v in ctx.prof_get().items() if v[1]}
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        prof = {k: round(v[0] / reps, 3) for k, v in ctx.prof_get().items() if v[1]}
         print(json.dumps({"kind": kind, "item_chunks": chunks or None, "communicator": "rccl, 1 rank" if chunks else None,
-                          "epoch_ms": round(ms, 3), "kernels_ms": prof}), flush=True)
+                          "exchange": exchange if chunks else None, "user_side": "unfused" if unfused else "fused",
+                          "epoch_ms": round(ms, 3), "kernels_ms": prof, "device_GB": round(ctx.device_bytes() / 1e9, 1)}), flush=True)
         ctx.close()
     comm.close()
 

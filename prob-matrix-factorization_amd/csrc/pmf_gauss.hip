@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
 //               range pre-rotated; reused for the two waves' partial means at the end
 //   gbuf [128] (Jacobi scales), wbuf [128] (right-hand side)
 #define PAIR_IMG 8256
-#define PAIR_LDS_FLOATS (PAIR_IMG + 512 + 128 + 128)
+#define PAIR_XBUF 1024   // exchange area: the row / column splits use 512 of it, the MFMA sweep two 128 x 4 pivot panels
+#define PAIR_LDS_FLOATS (PAIR_IMG + PAIR_XBUF + 128 + 128)
 
 __device__ __forceinline__ float pair_pad_diag(float inv_sigma2, float inv_eta2) { return (1.f - inv_eta2) / inv_sigma2; }
 
@@ -645,11 +646,190 @@ __device__ __forceinline__ void pair_solve_cols(const float *img, float *xbuf, f
     if (j < kpad) mout[j] = (j < K) ? mj * inv_sigma2 : 0.f;
 }
 
-template <int RW, bool FULL>
+
+// ---- 64 < K <= 128 on the matrix cores: block sweep, four pivots per step ------------------------------------------
+// The symmetric sweep of the K x K matrix as RANK-4 updates on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  The
+// Jacobi-scaled matrix B (padded to 16 TT rows with the identity) lives in the accumulator tiles of the block's two
+// wavefronts: wave 0 owns tile rows [0, TH), wave 1 the rest, every tile column; lane l of a tile holds column l & 15 of
+// rows 4 (l >> 4) + 0..3.  One step sweeps the pivot set Kb = {p .. p + 3}: with R = B[Kb, :] (4 x n, the pivot rows),
+// D = B[Kb, Kb] and U = R^T D^-1 (n x 4),
+//     B[i][j] -= U[i,:] R[:,j]  (i, j not in Kb),   B[i, Kb] = U[i,:],   B[Kb, j] = U[j,:]^T,   B[Kb, Kb] = -D^-1
+// -- four scalar sweeps in one.  All four cases come out of ONE MFMA per tile, without cancellation, when
+//   * the accumulator entries in the pivot rows and pivot columns are zeroed first,
+//   * the A operand (lane: row i, pivot index c) is -U[i][c], but D^-1[c][i - p] for the pivot rows themselves,
+//   * the B operand (lane: pivot index c, column j) is R[c][j], but -delta(c, j - p) for the pivot columns themselves:
+// a pivot row then receives  sum_c D^-1[c][k'] R[c][j] = U[j][k'],  a pivot column  sum_c (-U[i][c]) (-delta) = U[i][c'],
+// and the pivot block  sum_c D^-1[c][k'] (-delta(c, c')) = -D^-1.  The only data exchanged per step is the pivot panel R
+// (128 x 4 floats, double-buffered in LDS): its owner -- the 16 lanes that hold those four rows in their four
+// accumulator registers -- writes it as one float4 per column as soon as that tile row has been updated (the tile row
+// of the NEXT pivots is updated first), so the panel's write -> barrier -> read trip runs under the remaining MFMAs.
+// Every wave inverts the 4 x 4 pivot block itself (scalar sweep in registers, identical on all lanes).  Per step a
+// wave issues TH x TT MFMAs (32 at K = 128: 1024 matrix-pipe cycles) and about 150 VALU instructions, against the
+// 128 LDS-broadcast-bound scalar pivots x 85 VALU instructions of the splits above.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float rcp_nr(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);   // one Newton step: within an ulp of 1 / x
+}
+
+// Precondition: img / wbuf are complete and the block has synchronised.  rt = PAIR_XBUF floats.
+template <int TT>
+__device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gbuf, const float *wbuf, int K, int kpad,
+                                                int cov_stride, float inv_sigma2, float inv_eta2, float *vout, float *mout,
+                                                int wave, int lane) {
+    constexpr int TH = (TT + 1) / 2;
+    const int tid = 64 * wave + lane;
+    gbuf[tid] = 1.f / sqrtf(img[tid * (tid + 3) / 2] * inv_sigma2 + inv_eta2);   // (rows >= K: the padding diagonal gives 1)
+    __syncthreads();
+    const int lc = lane & 15, lg = lane >> 4;
+    const int base = wave ? TH : 0, nrows = wave ? TT - TH : TH;   // wave-uniform
+    f32x4 D[TH][TT];
+    float gj[TT];
+#pragma unroll
+    for (int J = 0; J < TT; ++J) gj[J] = gbuf[16 * J + lc];
+#pragma unroll
+    for (int ii = 0; ii < TH; ++ii) {
+        if (ii < nrows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (base + ii) + 4 * lg + r;
+                const float gi = gbuf[i] * inv_sigma2;
+                const int ti = i * (i + 1) / 2;
+#pragma unroll
+                for (int J = 0; J < TT; ++J) {
+                    const int j = 16 * J + lc;
+                    float v = img[i >= j ? ti + j : j * (j + 1) / 2 + i] * gi;
+                    if (i == j) v = fmaf(inv_eta2, gbuf[i], v);
+                    D[ii][J][r] = v * gj[J];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int J = 0; J < TT; ++J) D[ii][J] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the 16 lanes holding pivot rows 4 qg .. 4 qg + 3 of local tile row `ii` write them as the panel of a step
+    auto publish = [&](float *dst, int ii_local, int qg) {
+#pragma unroll
+        for (int ii = 0; ii < TH; ++ii)
+            if (ii == ii_local && lg == qg) {
+#pragma unroll
+                for (int J = 0; J < TT; ++J)
+                    *reinterpret_cast<float4 *>(dst + (16 * J + lc) * 4) = make_float4(D[ii][J][0], D[ii][J][1], D[ii][J][2], D[ii][J][3]);
+            }
+    };
+    const int steps = (K + 3) >> 2;
+    if (wave == 0) publish(rt, 0, 0);
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+        const int p = 4 * s, Ip = p >> 4, q = p & 15, qg = q >> 2;
+        const float *rb = rt + (s & 1) * 512;
+        __syncthreads();   // the panel of step s is visible; everybody has finished reading the other buffer
+        // D = B[Kb, Kb] (4 x 4, symmetric) -> -D^-1 by four scalar sweeps, identical on every lane
+        float m[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 col = *reinterpret_cast<const float4 *>(rb + (p + c) * 4);
+            m[0][c] = col.x; m[1][c] = col.y; m[2][c] = col.z; m[3][c] = col.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float pinv = rcp_nr(m[k][k]);
+            float u[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = m[i][k] * pinv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i != k && j != k) m[i][j] = fmaf(-u[i], m[k][j], m[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i != k) m[i][k] = m[k][i] = u[i];
+            m[k][k] = -pinv;
+        }
+        // dcol[k] = D^-1[k][lg] (this lane's pivot index as an A operand) = -m[k][lg]
+        float dcol[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dcol[k] = -(lg == 0 ? m[k][0] : lg == 1 ? m[k][1] : lg == 2 ? m[k][2] : m[k][3]);
+        const int cq = lc - q;                      // 0..3 when this lane's row / column index is a pivot
+        const bool piv = cq >= 0 && cq < 4;
+        const float apiv = cq == 0 ? dcol[0] : cq == 1 ? dcol[1] : cq == 2 ? dcol[2] : dcol[3];   // D^-1[lg][cq]
+        float bop[TT];
+#pragma unroll
+        for (int J = 0; J < TT; ++J) {
+            bop[J] = rb[(16 * J + lc) * 4 + lg];
+            if (J == Ip && piv) bop[J] = (lg == cq) ? -1.f : 0.f;
+        }
+        auto update_row = [&](auto ii_tag) {
+            constexpr int ii = decltype(ii_tag)::value;
+            const int I = base + ii;
+            const float4 x = *reinterpret_cast<const float4 *>(rb + (16 * I + lc) * 4);
+            float a = -fmaf(x.w, dcol[3], fmaf(x.z, dcol[2], fmaf(x.y, dcol[1], x.x * dcol[0])));
+            const bool prow = I == Ip;              // wave-uniform
+            if (prow && piv) a = apiv;
+#pragma unroll
+            for (int J = 0; J < TT; ++J) {
+                f32x4 c = D[ii][J];
+                const bool zero = (prow && lg == qg) || (J == Ip && piv);
+                if (zero) c = f32x4{0.f, 0.f, 0.f, 0.f};
+                D[ii][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bop[J], c, 0, 0, 0);
+            }
+        };
+        // the tile row that holds the next pivots first, then its panel, then the rest
+        const int pn = p + 4, inext = (s + 1 < steps) ? (pn >> 4) - base : -1;
+        auto for_rows = [&](auto &&body) {
+            if constexpr (TH > 0) body(std::integral_constant<int, 0>{});
+            if constexpr (TH > 1) body(std::integral_constant<int, 1>{});
+            if constexpr (TH > 2) body(std::integral_constant<int, 2>{});
+            if constexpr (TH > 3) body(std::integral_constant<int, 3>{});
+        };
+        for_rows([&](auto tag) {
+            if (decltype(tag)::value == inext) update_row(tag);
+        });
+        if (inext >= 0 && inext < nrows) publish(rt + ((s + 1) & 1) * 512, inext, (pn & 15) >> 2);
+        for_rows([&](auto tag) {
+            if (decltype(tag)::value != inext && decltype(tag)::value < nrows) update_row(tag);
+        });
+    }
+    // V = -(g_i g_j) B (packed lower triangle, staged in the LDS image and written out coalesced);
+    // m_i = inv_sigma2 * sum_j V[i][j] w_j: each wave has its rows complete
+    __syncthreads();   // (the image is free since the build; the last panel reads are done)
+    float xj[TT];
+#pragma unroll
+    for (int J = 0; J < TT; ++J) xj[J] = gj[J] * wbuf[16 * J + lc];
+#pragma unroll
+    for (int ii = 0; ii < TH; ++ii) {
+        if (ii < nrows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (base + ii) + 4 * lg + r;
+                const float gi = -gbuf[i];
+                float acc = 0.f;
+#pragma unroll
+                for (int J = 0; J < TT; ++J) {
+                    const int j = 16 * J + lc;
+                    const float b = D[ii][J][r] * gi;
+                    acc = fmaf(b, xj[J], acc);
+                    if (j <= i && i < K) img[i * (i + 1) / 2 + j] = b * gj[J];
+                }
+                acc = group_sum<16>(acc);
+                if (lc == 0 && i < kpad) mout[i] = i < K ? acc * inv_sigma2 : 0.f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    for (int qv = threadIdx.x * PMF_VEC; qv < cov_stride; qv += 128 * PMF_VEC) store4(vout + qv, load4(img + qv));
+}
+
+template <int RW, bool FULL, int MT = 0>
 __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<float> p) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *img = reinterpret_cast<float *>(smem_raw);
-    float *xbuf = img + PAIR_IMG, *gbuf = xbuf + 512, *wbuf = gbuf + 128;
+    float *xbuf = img + PAIR_IMG, *gbuf = xbuf + PAIR_XBUF, *wbuf = gbuf + 128;
     const int wave = rfl(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t idx = blockIdx.x;
     const int row = p.rows ? p.rows[idx] : (int)(p.row0 + idx);
@@ -672,7 +852,10 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
     }
     wbuf[j] = j < K ? p.src_w[(int64_t)row * p.src_w_stride + j] : 0.f;
     __syncthreads();
-    if constexpr (RW == 64)
+    if constexpr (MT > 0)
+        pair_solve_mfma<MT>(img, xbuf, gbuf, wbuf, K, p.kpad, p.cov_stride, p.inv_sigma2, p.inv_eta2,
+                            p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
+    else if constexpr (RW == 64)
         pair_solve_cols<FULL>(img, xbuf, gbuf, wbuf, K, p.kp, p.kpad, p.inv_sigma2, p.inv_eta2,
                               p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
     else
@@ -690,12 +873,12 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
 // solved in place by the same two waves (pair_solve_body).
 // NT = chunk columns per wave (host picks the smallest that covers ceil(chunks / 2) / 64):
 // 17 for K = 128 (1032 chunks per wave), 13 for K <= 112, 9 for K <= 92.
-template <int NT, bool FUSE, bool FULL, int RW = 64>
+template <int NT, bool FUSE, bool FULL, int RW = 64, int MT = 0>
 __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams<float> p, float inv_sigma2, float inv_eta2,
                                                                      float *cov_self, float *factor_self) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *img = reinterpret_cast<float *>(smem_raw);
-    float *xbuf = img + PAIR_IMG, *gbuf = xbuf + 512, *wbuf = gbuf + 128;
+    float *xbuf = img + PAIR_IMG, *gbuf = xbuf + PAIR_XBUF, *wbuf = gbuf + 128;
     const int wave = rfl(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const PmfTask t = load_task_uniform(p.tasks, blockIdx.x);
     const int h = lane >> 5, c = lane & 31;
@@ -875,7 +1058,10 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
             }
         }
         __syncthreads();
-        if constexpr (RW == 64)
+        if constexpr (MT > 0)
+            pair_solve_mfma<MT>(img, xbuf, gbuf, wbuf, K, kpad, stride, inv_sigma2, inv_eta2,
+                                cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
+        else if constexpr (RW == 64)
             pair_solve_cols<FULL>(img, xbuf, gbuf, wbuf, K, p.kp, kpad, inv_sigma2, inv_eta2,
                                   cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
         else
@@ -1372,10 +1558,30 @@ static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 gr
     }
 }
 
-// RW = rows per wave of the fused two-wave solve: 48 (a 96 x 96 sweep) for K <= 96, else 64
+// RW = rows per wave of the fused two-wave solve: 48 (a 96 x 96 sweep) for K <= 96, else 64; MT = 16-row tiles per
+// dimension of the MFMA block sweep (the default; PMF_GAUSS_VALU_SOLVE selects the VALU splits for comparison)
+template <int NT, int MT>
+static void launch_accum_mfma128_mt(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, size_t smem, float is2, float ie2,
+                                    float *cov, float *fac) {
+    hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 64, MT>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+}
+
 template <int NT>
 static void launch_accum_mfma128(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, size_t smem, bool fuse, float is2,
                                  float ie2, float *cov, float *fac) {
+    if (fuse && !ctx->gauss_valu_solve) {
+        const int mt = (ctx->K + 15) / 16;   // 5..8
+        if constexpr (NT == 9) {
+            if (mt <= 5) launch_accum_mfma128_mt<NT, 5>(ctx, p, grid, smem, is2, ie2, cov, fac);
+            else launch_accum_mfma128_mt<NT, 6>(ctx, p, grid, smem, is2, ie2, cov, fac);
+        } else if constexpr (NT == 13) {
+            if (mt <= 6) launch_accum_mfma128_mt<NT, 6>(ctx, p, grid, smem, is2, ie2, cov, fac);
+            else launch_accum_mfma128_mt<NT, 7>(ctx, p, grid, smem, is2, ie2, cov, fac);
+        } else {
+            launch_accum_mfma128_mt<NT, 8>(ctx, p, grid, smem, is2, ie2, cov, fac);
+        }
+        return;
+    }
     if (fuse) {
         if constexpr (NT == 17) {
             if (ctx->K == 128) {
@@ -1561,7 +1767,14 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (std::is_same<T, float>::value && !ctx->gauss_lds_solve && ctx->K <= 128) {
         if constexpr (std::is_same<T, float>::value) {
             const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
-            if (ctx->K == 128)
+            if (!ctx->gauss_valu_solve) {
+                switch ((ctx->K + 15) / 16) {
+                    case 5: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 5>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                    case 6: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 6>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                    case 7: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 7>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                    default: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 8>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                }
+            } else if (ctx->K == 128)
                 hipLaunchKernelGGL((gauss_solve_pair_kernel<64, true>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
             else if (ctx->K <= 80)
                 hipLaunchKernelGGL((gauss_solve_pair_kernel<40, false>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);

@@ -306,346 +306,21 @@ __global__ __launch_bounds__(256) void gauss_solve_reg_kernel(SolveParams<T> p) 
                             p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, lane);
 }
 
-// 64 < K <= 128, fp32: the rotating sweep shared by the TWO wavefronts of a 128-thread block, split by
-// ROWS: wave w owns rows [w RW, (w + 1) RW) of the padded RT x RT matrix (RT = 2 RW; RW = 48 for K <= 96,
-// 64 above) for ALL columns -- lane l holds columns l and l + 64, each as RW / 2 aligned register PAIRS
-// (rows 2p, 2p + 1), so the rank-1 update is one v_pk_fma_f32 per two rows and column.
-//
-// Per pivot the wave that owns the pivot row publishes it in LDS; by symmetry that row is also the pivot
-// column, so the per-row scalars s_i come back as uniform-address (broadcast) 8-byte LDS reads.  A wave needs
-// the scalars of ITS rows only -- RW / 2 reads per pivot, shared by its two columns -- which is half the LDS
-// return traffic of the earlier column split (every wave read all 128 scalars); the sweep was bound by
-// exactly that traffic.  The owner rotates its rows through the registers (two pivots per
-// trip: step A updates in place, step B moves every row down one pair, the pivot row to the top), so the
-// pivot row is always register 0 and nothing is indexed dynamically; its scalars are published pre-rotated
-// (xr), the other wave reads its own from the natural copy (xn).  Pivots [0, RW) belong to wave 0, which is
-// back in place when wave 1 takes over for pivots [RW, K); only the K real pivots are swept (the padding
-// block is the identity and stays one).
-//
-// LDS layout shared with the K <= 128 accumulate kernel:
+// 64 < K <= 128, fp32: a row is handled by the TWO wavefronts of a 128-thread block.
+// LDS layout shared by the accumulate kernel and the solve:
 //   img [8256]  full 128-row packed lower triangle: S for rows < K; for the padding rows
 //               >= K zeros with a diagonal chosen so that P_ii = S_ii/sigma2 + 1/eta2 = 1,
 //               which removes every K-dependent mask from the register build
-//   xbuf [512]  xn [2][128] pivot row by column (double-buffered by step), xr [2][64] the owner's own
-//               range pre-rotated; reused for the two waves' partial means at the end
+//   xbuf [1024] the MFMA sweep's two 128 x 4 pivot panels (double-buffered by step)
 //   gbuf [128] (Jacobi scales), wbuf [128] (right-hand side)
+// (Rounds 1-2 swept the matrix on the VALU, split between the two waves by rows (K <= 96) or by columns, one scalar
+//  pivot at a time with the pivot row broadcast through LDS -- 85 VALU instructions and a 128-scalar LDS round trip per
+//  pivot; the block sweep below replaced them in round 3: profiles/r03_solve_mfma_vs_valu.jsonl.)
 #define PAIR_IMG 8256
-#define PAIR_XBUF 1024   // exchange area: the row / column splits use 512 of it, the MFMA sweep two 128 x 4 pivot panels
+#define PAIR_XBUF 1024   // two 128 x 4 pivot panels
 #define PAIR_LDS_FLOATS (PAIR_IMG + PAIR_XBUF + 128 + 128)
 
 __device__ __forceinline__ float pair_pad_diag(float inv_sigma2, float inv_eta2) { return (1.f - inv_eta2) / inv_sigma2; }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Precondition: img / wbuf are complete and the block has synchronised.
-// (instantiated with RW = 48; FULL would be K == 2 RW: no rotation left at the end)
-template <int RW, bool FULL>
-__device__ __forceinline__ void pair_solve_body(const float *img, float *xbuf, float *gbuf, const float *wbuf, int K,
-                                                int kp, int kpad, float inv_sigma2, float inv_eta2, float *vout,
-                                                float *mout, int wave, int lane) {
-    constexpr int RT = 2 * RW, NP = RW / 2;
-    const int t = 64 * wave + lane;
-    gbuf[t] = 1.f / sqrtf(img[t * (t + 3) / 2] * inv_sigma2 + inv_eta2);
-    __syncthreads();
-    const int j0 = lane, j1 = lane + 64;
-    const float g0 = gbuf[j0], g1 = gbuf[j1];
-    const int rbase = wave * RW;
-    const bool ghost1 = RT < 128 && j1 >= RT;   // columns past the padded matrix (RW = 48, lanes >= 32)
-    f32x2 B0[NP], B1[NP];                       // column j0 / j1, rows (2p, 2p + 1) of this wave
-    const int t0 = j0 * (j0 + 1) / 2, t1 = j1 * (j1 + 1) / 2;   // packed offsets of the lane's two columns as ROWS
-    const float s0 = g0 * inv_sigma2, s1 = ghost1 ? 0.f : g1 * inv_sigma2;
-    const float e0 = g0 * inv_eta2, e1 = g1 * inv_eta2;
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int R = rbase + i;                 // wave-uniform
-        const int tR = R * (R + 1) / 2;
-        const float gR = gbuf[R];
-        // element (R, j) of the symmetric matrix lives at max(R, j) (max + 1) / 2 + min(R, j)
-        float v0 = img[R < j0 ? t0 + R : tR + j0] * s0;
-        float v1 = img[R < j1 ? t1 + R : tR + j1] * s1;
-        if (R == j0) v0 += e0;
-        if (R == j1) v1 += e1;
-        B0[i >> 1][i & 1] = v0 * gR;
-        B1[i >> 1][i & 1] = v1 * gR;
-        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from piling up in VGPRs
-    }
-    float *xn = xbuf, *xr = xbuf + 256;
-    // the owner's lanes publish the pivot row: natural order for everybody's u and the other wave's
-    // scalars, and -- for the columns of the owner's own row range -- rotated by the trip base kl
-    auto publish = [&](int buf, float v0, float v1, int kl, int obase) {
-        xn[buf * 128 + j0] = v0;
-        xn[buf * 128 + j1] = v1;
-        int d0 = j0 - obase - kl, d1 = j1 - obase - kl;
-        if (j0 >= obase && j0 < obase + RW) xr[buf * 64 + (d0 < 0 ? d0 + RW : d0)] = v0;
-        if (j1 >= obase && j1 < obase + RW) xr[buf * 64 + (d1 < 0 ? d1 + RW : d1)] = v1;
-    };
-    // in-place update of every row pair of this wave (both columns) from the scalar pairs at sc2
-    constexpr int SB = 4;   // scalar pairs per batch: the sweep has no registers to spare at RW = 64
-    auto update_in_place = [&](const f32x2 *sc2, f32x2 uc0, f32x2 uc1) {
-#pragma unroll
-        for (int p0 = 0; p0 < NP; p0 += SB) {
-            f32x2 sc[SB];
-#pragma unroll
-            for (int q = 0; q < SB; ++q) sc[q] = sc2[p0 + q];
-#pragma unroll
-            for (int q = 0; q < SB; ++q) {
-                B0[p0 + q] = __builtin_elementwise_fma(-sc[q], uc0, B0[p0 + q]);
-                B1[p0 + q] = __builtin_elementwise_fma(-sc[q], uc1, B1[p0 + q]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // One trip = two pivots (local rows kl, kl + 1 of the owner wave `o`).  The owner's and the other wave's
-    // trips are separate loops -- a join of the rotating and the in-place form inside one loop would cost
-    // a register copy per row pair and trip.
-    auto pivot_terms = [&](int buf, int k, float &pinv, float &u0, float &u1, f32x2 &uc0, f32x2 &uc1) {
-        pinv = 1.f / xn[buf * 128 + k];
-        u0 = xn[buf * 128 + j0] * pinv;
-        u1 = xn[buf * 128 + j1] * pinv;
-        const float c0 = (j0 == k) ? (1.f - pinv) : u0, c1 = (j1 == k) ? (1.f - pinv) : u1;
-        uc0 = f32x2{c0, c0};
-        uc1 = f32x2{c1, c1};
-    };
-    // The owner looks one pivot ahead: as soon as a step has updated the row that is the NEXT pivot, that row is
-    // published, so the write -> barrier -> read round trip of the next step runs under the rest of this
-    // step's updates.  A step therefore STARTS with the barrier for a row published during the previous
-    // step (the very first row of a phase by `owner_begin`).
-    auto update_pairs = [&](const f32x2 *sc2, f32x2 uc0, f32x2 uc1, int first) {   // pairs [first, NP) in place
-#pragma unroll
-        for (int p0 = first; p0 < NP; p0 += SB) {
-            f32x2 sc[SB];
-#pragma unroll
-            for (int q = 0; q < SB; ++q)
-                if (p0 + q < NP) sc[q] = sc2[p0 + q];
-#pragma unroll
-            for (int q = 0; q < SB; ++q)
-                if (p0 + q < NP) {
-                    B0[p0 + q] = __builtin_elementwise_fma(-sc[q], uc0, B0[p0 + q]);
-                    B1[p0 + q] = __builtin_elementwise_fma(-sc[q], uc1, B1[p0 + q]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto owner_begin = [&](int obase) { publish(0, B0[0][0], B1[0][0], 0, obase); };
-    // step A as the owner: pivot = register 0, element 0; rows stay.  `ahead`: row kl + 1 is a pivot too.
-    auto owner_step_a = [&](int obase, int kl, bool ahead) {
-        const int k = obase + kl;
-        __syncthreads();
-        float pinv, u0, u1;
-        f32x2 uc0, uc1;
-        pivot_terms(0, k, pinv, u0, u1, uc0, uc1);
-        const f32x2 *sA = reinterpret_cast<const f32x2 *>(xr);
-        B0[0] = __builtin_elementwise_fma(-sA[0], uc0, B0[0]);
-        B1[0] = __builtin_elementwise_fma(-sA[0], uc1, B1[0]);
-        B0[0][0] = (j0 == k) ? -pinv : u0;   // the pivot row itself
-        B1[0][0] = (j1 == k) ? -pinv : u1;
-        if (ahead) publish(1, B0[0][1], B1[0][1], kl, obase);
-        update_pairs(sA, uc0, uc1, 1);
-    };
-    // `ahead`: the row that moves into register 0 (local row kl + 2) is the next trip's first pivot
-    auto owner_trip = [&](int obase, int kl, bool ahead) {
-        owner_step_a(obase, kl, true);
-        // step B: pivot = register 0, element 1; every row moves down one pair, the pivot row to the top
-        const int k = obase + kl + 1;
-        __syncthreads();
-        float pinv, u0, u1;
-        f32x2 uc0, uc1;
-        pivot_terms(1, k, pinv, u0, u1, uc0, uc1);
-        const f32x2 *sB = reinterpret_cast<const f32x2 *>(xr + 64);
-        f32x2 f0 = __builtin_elementwise_fma(-sB[0], uc0, B0[0]);   // row kl (kept) | pivot row (replaced)
-        f32x2 f1 = __builtin_elementwise_fma(-sB[0], uc1, B1[0]);
-        B0[0] = __builtin_elementwise_fma(-sB[1], uc0, B0[1]);      // local rows kl + 2, kl + 3 arrive in register 0
-        B1[0] = __builtin_elementwise_fma(-sB[1], uc1, B1[1]);
-        if (ahead) publish(0, B0[0][0], B1[0][0], kl + 2, obase);
-#pragma unroll
-        for (int p0 = 2; p0 < NP; p0 += SB) {
-            f32x2 sc[SB];
-#pragma unroll
-            for (int q = 0; q < SB; ++q)
-                if (p0 + q < NP) sc[q] = sB[p0 + q];
-#pragma unroll
-            for (int q = 0; q < SB; ++q)
-                if (p0 + q < NP) {
-                    B0[p0 + q - 1] = __builtin_elementwise_fma(-sc[q], uc0, B0[p0 + q]);
-                    B1[p0 + q - 1] = __builtin_elementwise_fma(-sc[q], uc1, B1[p0 + q]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f0[1] = (j0 == k) ? -pinv : u0;
-        f1[1] = (j1 == k) ? -pinv : u1;
-        B0[NP - 1] = f0;
-        B1[NP - 1] = f1;
-    };
-    // the other wave: its rows are in place, its scalars are the natural slice xn[rbase ...]
-    auto other_step = [&](int buf, int k) {
-        __syncthreads();
-        float pinv, u0, u1;
-        f32x2 uc0, uc1;
-        pivot_terms(buf, k, pinv, u0, u1, uc0, uc1);
-        update_in_place(reinterpret_cast<const f32x2 *>(xn + buf * 128 + rbase), uc0, uc1);
-    };
-    const int np1 = ((FULL ? RT : K) - RW) >> 1;          // pivot pairs of wave 1's phase
-    const bool tail = !FULL && (((K - RW) & 1) != 0);     // odd K: one last pivot, rows stay where they are
-    if (wave == 0) {
-        owner_begin(0);
-#pragma unroll 1
-        for (int kk = 0; kk < NP; ++kk) owner_trip(0, 2 * kk, kk + 1 < NP);
-#pragma unroll 1
-        for (int kk = 0; kk < np1; ++kk) {
-            other_step(0, RW + 2 * kk);
-            other_step(1, RW + 2 * kk + 1);
-        }
-        if (tail) other_step(0, RW + 2 * np1);
-    } else {
-#pragma unroll 1
-        for (int kk = 0; kk < NP; ++kk) {
-            other_step(0, 2 * kk);
-            other_step(1, 2 * kk + 1);
-        }
-        // (wave 0's last step reads buffer 1: publishing into buffer 0 here cannot disturb it)
-        if (np1 > 0 || tail) owner_begin(RW);
-#pragma unroll 1
-        for (int kk = 0; kk < np1; ++kk) owner_trip(RW, 2 * kk, kk + 1 < np1 || tail);
-        if (tail) owner_step_a(RW, 2 * np1, false);
-    }
-    const int rot1 = 2 * np1;   // rotation wave 1's registers are left with
-    // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i  (each wave sums over its rows; added below)
-    // (the bound of the packed output as a VECTOR value: a scalar `i < K` would make the
-    //  compiler keep one mask per row in SGPRs and spill them)
-    int kpv = kp;
-    asm volatile("" : "+v"(kpv));
-    const int rot = (FULL || wave == 0) ? 0 : rot1;   // register i holds local row (i + rot) mod RW
-    float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        int l = i + rot;
-        if (!FULL && l >= RW) l -= RW;
-        const int R = FULL ? rbase + i : rbase + l;
-        const float gR = gbuf[R], wR = wbuf[R];
-        const float v0 = -B0[i >> 1][i & 1] * g0 * gR, v1 = -B1[i >> 1][i & 1] * g1 * gR;
-        m0 = fmaf(v0, wR, m0);
-        m1 = fmaf(v1, wR, m1);
-        // (row index and offset as VECTOR values: with scalar ones the compiler hoists one lane mask per row
-        //  into SGPRs -- 2 x RW of them -- and spills them)
-        int Rv = R, at = R * (R + 1) / 2;
-        asm volatile("" : "+v"(Rv), "+v"(at));
-        if (j0 <= Rv && at + j0 < kpv) vout[at + j0] = v0;
-        if (j1 <= Rv && at + j1 < kpv) vout[at + j1] = v1;
-        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();   // the last pivot step's reads of xbuf are done in both waves
-    xbuf[wave * 128 + j0] = m0;
-    xbuf[wave * 128 + j1] = m1;
-    __syncthreads();
-    if (t < kpad) mout[t] = (t < K) ? (xbuf[t] + xbuf[128 + t]) * inv_sigma2 : 0.f;
-}
-
-// ---- 96 < K <= 128: the COLUMN split ------------------------------------------------------------------
-// Wave w owns columns [64w, 64w + 64) of all 128 rows (128 row registers per lane, lane = column); both waves
-// publish their half of the pivot row each step and read all 128 row scalars back.  Twice the LDS return
-// traffic of the row split above, but its single loop keeps the 128 row registers free of copies and spills,
-// which the row split at RW = 64 does not (measured at the C4 shard size: 739 ms per epoch against 791 ms), so
-// K > 96 stays on it; xbuf here is [2][256] exchange buffers.
-// Precondition: img / wbuf are complete and the block has synchronised.
-// FULL: K == 128, every register index is its row (static LDS offsets in the epilogue).
-template <bool FULL>
-__device__ __forceinline__ void pair_solve_cols(const float *img, float *xbuf, float *gbuf, const float *wbuf, int K,
-                                                int kp, int kpad, float inv_sigma2, float inv_eta2, float *vout,
-                                                float *mout, int wave, int lane) {
-    constexpr int KR = 128;
-    const int j = 64 * wave + lane;
-    const float g = 1.f / sqrtf(img[j * (j + 3) / 2] * inv_sigma2 + inv_eta2);
-    gbuf[j] = g;
-    __syncthreads();
-    // Rows are kept in PAIRS of registers (B2[i] = rows 2i, 2i+1 of this lane's column) so that the
-    // rank-1 update runs as v_pk_fma_f32 -- two rows per instruction, the pair of row scalars coming
-    // from one aligned LDS read.
-    f32x2 B2[KR / 2];
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        float v = img[hi * (hi + 1) / 2 + lo] * inv_sigma2;
-        if (i == j) v += inv_eta2;
-        B2[i >> 1][i & 1] = v * g * gbuf[i];
-        if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from piling up in VGPRs
-    }
-    // Two pivots per trip.  At the top of a trip register r holds row (k + r) mod 128, k even.
-    //   step A  pivot row k   = register 0: rows updated in place;
-    //   step B  pivot row k+1 = register 1: rows updated and moved down two registers
-    //           (row k -> register 126, the pivot row -> register 127),
-    // so both steps work on aligned register pairs.  The lane that owns column c publishes its pivot
-    // element at xb[(c - k) mod 128]: xb[r] is then the pivot row's element in column k + r, which by
-    // symmetry is the scalar s_r of register r, at a fixed, 16-byte aligned address.
-    // Only the K real pivots are swept (the padding block is the identity and stays one).
-    const int npair = (FULL ? KR : K) >> 1;
-    const f32x2 *xa2 = reinterpret_cast<const f32x2 *>(xbuf), *xb2 = reinterpret_cast<const f32x2 *>(xbuf + 128);
-    auto step_a = [&](int k) {
-        const float v = B2[0][0];
-        xbuf[(j - k) & (KR - 1)] = v;
-        __syncthreads();
-        const float pinv = 1.f / xbuf[0];
-        const float u = v * pinv;
-        const float uc = (j == k) ? (1.f - pinv) : u;
-        const f32x2 uc2 = {uc, uc};
-#pragma unroll
-        for (int i0 = 0; i0 < KR / 2; i0 += 8) {   // batches keep the live set small
-            f32x2 sc[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) sc[q] = xa2[i0 + q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) B2[i0 + q] = __builtin_elementwise_fma(-sc[q], uc2, B2[i0 + q]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        B2[0][0] = (j == k) ? -pinv : u;   // the pivot row itself
-    };
-#pragma unroll 1
-    for (int kk = 0; kk < npair; ++kk) {
-        const int k = 2 * kk;
-        step_a(k);
-        {
-            const float v = B2[0][1];
-            xbuf[128 + ((j - k) & (KR - 1))] = v;
-            __syncthreads();
-            const float pinv = 1.f / xbuf[128 + 1];
-            const float u = v * pinv;
-            const float uc = (j == k + 1) ? (1.f - pinv) : u;
-            const f32x2 uc2 = {uc, uc};
-            f32x2 first = __builtin_elementwise_fma(-xb2[0], uc2, B2[0]);   // row k (kept) | pivot row (replaced)
-#pragma unroll
-            for (int i0 = 1; i0 < KR / 2; i0 += 8) {
-                f32x2 sc[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (i0 + q < KR / 2) sc[q] = xb2[i0 + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (i0 + q < KR / 2) B2[i0 + q - 1] = __builtin_elementwise_fma(-sc[q], uc2, B2[i0 + q]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            first[1] = (j == k + 1) ? -pinv : u;
-            B2[KR / 2 - 1] = first;
-        }
-    }
-    if (!FULL && (K & 1)) step_a(K - 1);   // odd K: the last pivot, rows stay where they are
-    // V = -(g_i g_j) B ;  m_j = inv_sigma2 * sum_i V[i][j] w_i
-    // (the bound of the packed output as a VECTOR value: a scalar `i < K` would make the
-    //  compiler keep 128 masks in SGPRs and spill them)
-    int kpv = kp, kv = 2 * npair;   // register i holds row (i + 2 npair) mod 128
-    asm volatile("" : "+v"(kpv));
-    asm volatile("" : "+v"(kv));
-    float mj = 0.f;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        const int r = FULL ? i : ((i + kv) & (KR - 1));   // the row register i holds
-        const float vij = -B2[i >> 1][i & 1] * g * gbuf[r];
-        mj = fmaf(vij, wbuf[r], mj);
-        const int at = r * (r + 1) / 2 + j;
-        if (j <= r && at < kpv) vout[at] = vij;
-        if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (j < kpad) mout[j] = (j < K) ? mj * inv_sigma2 : 0.f;
-}
-
 
 // ---- 64 < K <= 128 on the matrix cores: block sweep, four pivots per step ------------------------------------------
 // The symmetric sweep of the K x K matrix as RANK-4 updates on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  The
@@ -665,7 +340,7 @@ __device__ __forceinline__ void pair_solve_cols(const float *img, float *xbuf, f
 // of the NEXT pivots is updated first), so the panel's write -> barrier -> read trip runs under the remaining MFMAs.
 // Every wave inverts the 4 x 4 pivot block itself (scalar sweep in registers, identical on all lanes).  Per step a
 // wave issues TH x TT MFMAs (32 at K = 128: 1024 matrix-pipe cycles) and about 150 VALU instructions, against the
-// 128 LDS-broadcast-bound scalar pivots x 85 VALU instructions of the splits above.
+// 128 LDS-broadcast-bound scalar pivots x 85 VALU instructions of the VALU splits it replaced.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float rcp_nr(float x) {
@@ -825,7 +500,7 @@ __device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gb
     for (int qv = threadIdx.x * PMF_VEC; qv < cov_stride; qv += 128 * PMF_VEC) store4(vout + qv, load4(img + qv));
 }
 
-template <int RW, bool FULL, int MT = 0>
+template <int MT>
 __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<float> p) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *img = reinterpret_cast<float *>(smem_raw);
@@ -852,15 +527,8 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
     }
     wbuf[j] = j < K ? p.src_w[(int64_t)row * p.src_w_stride + j] : 0.f;
     __syncthreads();
-    if constexpr (MT > 0)
-        pair_solve_mfma<MT>(img, xbuf, gbuf, wbuf, K, p.kpad, p.cov_stride, p.inv_sigma2, p.inv_eta2,
-                            p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
-    else if constexpr (RW == 64)
-        pair_solve_cols<FULL>(img, xbuf, gbuf, wbuf, K, p.kp, p.kpad, p.inv_sigma2, p.inv_eta2,
-                              p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
-    else
-        pair_solve_body<RW, FULL>(img, xbuf, gbuf, wbuf, K, p.kp, p.kpad, p.inv_sigma2, p.inv_eta2,
-                                  p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
+    pair_solve_mfma<MT>(img, xbuf, gbuf, wbuf, K, p.kpad, p.cov_stride, p.inv_sigma2, p.inv_eta2,
+                        p.cov + (int64_t)row * p.cov_stride, p.factor + (int64_t)row * p.kpad, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -870,10 +538,10 @@ __global__ __launch_bounds__(128, 2) void gauss_solve_pair_kernel(SolveParams<fl
 // 16-byte chunks per lane) and owns five of the ten lower 32x32 blocks of sum m m^T
 // (wave 0: (0,0) (1,0) (1,1) (2,0) (2,1); wave 1: (2,2) (3,0) (3,1) (3,2) (3,3)).
 // Both waves fold their blocks into the shared LDS image; a complete row is then
-// solved in place by the same two waves (pair_solve_body).
+// solved in place by the same two waves (pair_solve_mfma).
 // NT = chunk columns per wave (host picks the smallest that covers ceil(chunks / 2) / 64):
 // 17 for K = 128 (1032 chunks per wave), 13 for K <= 112, 9 for K <= 92.
-template <int NT, bool FUSE, bool FULL, int RW = 64, int MT = 0>
+template <int NT, bool FUSE, int MT = 0>
 __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams<float> p, float inv_sigma2, float inv_eta2,
                                                                      float *cov_self, float *factor_self) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1044,7 +712,7 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
         wbuf[64 * wave + 32 + c] = wB;
     }
     __syncthreads();
-    if (FUSE && t.slot < 0) {
+    if constexpr (FUSE && MT > 0) if (t.slot < 0) {
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
             const int q = q_begin + lane + 64 * s;
@@ -1058,15 +726,8 @@ __global__ __launch_bounds__(128, 2) void gauss_accum_mfma128_kernel(GaussParams
             }
         }
         __syncthreads();
-        if constexpr (MT > 0)
-            pair_solve_mfma<MT>(img, xbuf, gbuf, wbuf, K, kpad, stride, inv_sigma2, inv_eta2,
-                                cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
-        else if constexpr (RW == 64)
-            pair_solve_cols<FULL>(img, xbuf, gbuf, wbuf, K, p.kp, kpad, inv_sigma2, inv_eta2,
-                                  cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
-        else
-            pair_solve_body<RW, FULL>(img, xbuf, gbuf, wbuf, K, p.kp, kpad, inv_sigma2, inv_eta2,
-                                      cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
+        pair_solve_mfma<MT>(img, xbuf, gbuf, wbuf, K, kpad, stride, inv_sigma2, inv_eta2,
+                            cov_self + (int64_t)t.row * stride, factor_self + (int64_t)t.row * kpad, wave, lane);
         return;
     }
     float *out_s, *out_w;
@@ -1558,54 +1219,25 @@ static void launch_accum_mfma(pmf_ctx *ctx, const GaussParams<float> &p, dim3 gr
     }
 }
 
-// RW = rows per wave of the fused two-wave solve: 48 (a 96 x 96 sweep) for K <= 96, else 64; MT = 16-row tiles per
-// dimension of the MFMA block sweep (the default; PMF_GAUSS_VALU_SOLVE selects the VALU splits for comparison)
-template <int NT, int MT>
-static void launch_accum_mfma128_mt(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, size_t smem, float is2, float ie2,
-                                    float *cov, float *fac) {
-    hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 64, MT>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
-}
-
+// MT = 16-row tiles per dimension of the fused MFMA block sweep (ceil(K / 16): 5..8)
 template <int NT>
 static void launch_accum_mfma128(pmf_ctx *ctx, const GaussParams<float> &p, dim3 grid, size_t smem, bool fuse, float is2,
                                  float ie2, float *cov, float *fac) {
-    if (fuse && !ctx->gauss_valu_solve) {
-        const int mt = (ctx->K + 15) / 16;   // 5..8
-        if constexpr (NT == 9) {
-            if (mt <= 5) launch_accum_mfma128_mt<NT, 5>(ctx, p, grid, smem, is2, ie2, cov, fac);
-            else launch_accum_mfma128_mt<NT, 6>(ctx, p, grid, smem, is2, ie2, cov, fac);
-        } else if constexpr (NT == 13) {
-            if (mt <= 6) launch_accum_mfma128_mt<NT, 6>(ctx, p, grid, smem, is2, ie2, cov, fac);
-            else launch_accum_mfma128_mt<NT, 7>(ctx, p, grid, smem, is2, ie2, cov, fac);
-        } else {
-            launch_accum_mfma128_mt<NT, 8>(ctx, p, grid, smem, is2, ie2, cov, fac);
-        }
+    if (!fuse) {
+        hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, false>), grid, dim3(128), smem, ctx->stream, p, 0.f, 0.f,
+                           (float *)nullptr, (float *)nullptr);
         return;
     }
-    if (fuse) {
-        if constexpr (NT == 17) {
-            if (ctx->K == 128) {
-                hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, true, 64>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
-                return;
-            }
-        }
-        if constexpr (NT == 9) {
-            if (ctx->K <= 80) {   // an 80-row sweep (K = 70 is in the reference's grid)
-                hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 40>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
-                return;
-            }
-        }
-        if constexpr (NT <= 13) {
-            if (ctx->K <= 96) {
-                hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 48>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
-                return;
-            }
-        }
-        if constexpr (NT >= 13)
-            hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, false, 64>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
-    } else
-        hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, false, false>), grid, dim3(128), smem, ctx->stream, p, 0.f, 0.f,
-                           (float *)nullptr, (float *)nullptr);
+    const int mt = (ctx->K + 15) / 16;
+    if constexpr (NT == 9) {          // K <= 92
+        if (mt <= 5) hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, 5>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+        else hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, 6>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+    } else if constexpr (NT == 13) {  // K <= 112
+        if (mt <= 6) hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, 6>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+        else hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, 7>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+    } else {
+        hipLaunchKernelGGL((gauss_accum_mfma128_kernel<NT, true, 8>), grid, dim3(128), smem, ctx->stream, p, is2, ie2, cov, fac);
+    }
 }
 
 // *fused is set when the kernel also solved every single-task row (K = 64 fp32,
@@ -1767,21 +1399,12 @@ static int run_factor_solve(pmf_ctx *ctx, int side, const void *stats, double si
     else if (std::is_same<T, float>::value && !ctx->gauss_lds_solve && ctx->K <= 128) {
         if constexpr (std::is_same<T, float>::value) {
             const size_t smem = (size_t)PAIR_LDS_FLOATS * sizeof(float);
-            if (!ctx->gauss_valu_solve) {
-                switch ((ctx->K + 15) / 16) {
-                    case 5: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 5>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
-                    case 6: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 6>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
-                    case 7: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 7>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
-                    default: hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false, 8>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
-                }
-            } else if (ctx->K == 128)
-                hipLaunchKernelGGL((gauss_solve_pair_kernel<64, true>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
-            else if (ctx->K <= 80)
-                hipLaunchKernelGGL((gauss_solve_pair_kernel<40, false>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
-            else if (ctx->K <= 96)
-                hipLaunchKernelGGL((gauss_solve_pair_kernel<48, false>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
-            else
-                hipLaunchKernelGGL((gauss_solve_pair_kernel<64, false>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp);
+            switch ((ctx->K + 15) / 16) {
+                case 5: hipLaunchKernelGGL((gauss_solve_pair_kernel<5>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                case 6: hipLaunchKernelGGL((gauss_solve_pair_kernel<6>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                case 7: hipLaunchKernelGGL((gauss_solve_pair_kernel<7>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+                default: hipLaunchKernelGGL((gauss_solve_pair_kernel<8>), dim3((unsigned)sp.n), dim3(128), smem, ctx->stream, sp); break;
+            }
         }
     } else {
         const int K = ctx->K;

@@ -1,12 +1,12 @@
 """Copy the round's rocprofv3 summaries from gpurun_out/prof_<tag>/ (scratch) into profiles/ (tracked):
 kernel-stats CSVs (device kernels only, library / copy kernels dropped), the bench lines printed under the
-profiler, and the per-K sweep lines.    python tools/collect_profiles.py r02"""
+profiler, and the per-K sweep lines.    python tools/collect_profiles.py r03"""
 import csv
 import glob
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")

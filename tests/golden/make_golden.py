@@ -238,7 +238,9 @@ def gen_model_case(kind, seed, K):
 # per side), predict, and the validation RMSE / MacroMAE after each of 5 iterations (which pins the
 # whole state at every iteration through the reference's own evaluate_* functions).
 HEADLINE = [("gauss_bias", 30), ("gauss_bias", 64), ("gauss_bias", 128), ("gauss", 64),
-            ("poisson", 40), ("poisson", 64), ("hpf", 20), ("hpf", 64)]
+            ("poisson", 40), ("poisson", 64), ("hpf", 20), ("hpf", 64),
+            # round 3: the two odd tile counts of the 64 < K <= 128 MFMA block sweep (5 and 7 tiles of 16 rows; K = 128 is 8)
+            ("gauss_bias", 80), ("gauss_bias", 112)]
 HEADLINE_KEYS = {"gauss_bias": ["m_theta", "m_beta", "m_user_bias", "m_item_bias"], "gauss": ["m_theta", "m_beta"],
                  "poisson": ["E_theta", "E_beta", "a_theta", "b_beta"],
                  "hpf": ["E_theta", "E_beta", "E_xi", "E_eta", "gamma_a_theta", "gamma_b_beta", "gamma_b_xi", "gamma_b_eta"]}
@@ -400,6 +402,8 @@ def main():
         return
     if not only or "headline" in only:
         for kind, K in HEADLINE:
+            if "new" in only and os.path.exists(os.path.join(OUT, f"hk_{kind}_k{K}.npz")):
+                continue        # `headline new`: only the cases that have no file yet (existing fixtures stay byte-identical)
             path = os.path.join(OUT, f"hk_{kind}_k{K}.npz")
             np.savez_compressed(path, **gen_headline_case(kind, K))
             print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -40,7 +40,8 @@ def _model(kind, meta, max_iter, tol, dtype):
 
 def test_fixture_set_covers_the_headline_configurations():
     assert set(CASES) == {"hk_gauss_bias_k30", "hk_gauss_bias_k64", "hk_gauss_bias_k128", "hk_gauss_k64",
-                          "hk_poisson_k40", "hk_poisson_k64", "hk_hpf_k20", "hk_hpf_k64"}
+                          "hk_poisson_k40", "hk_poisson_k64", "hk_hpf_k20", "hk_hpf_k64",
+                          "hk_gauss_bias_k80", "hk_gauss_bias_k112"}     # (round 3: 5 and 7 tiles of the MFMA block sweep)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -141,8 +141,8 @@ HEADLINE_KEYS = {"gauss_bias": ["m_theta", "m_beta", "m_user_bias", "m_item_bias
 def test_headline_fixture_set_is_complete():
     names = {os.path.basename(p)[3:-4] for p in HEADLINE}
     assert names == {"gauss_bias_k30", "gauss_bias_k64", "gauss_bias_k128", "gauss_k64", "poisson_k40", "poisson_k64",
-                     "hpf_k20", "hpf_k64"}
-    assert sum(os.path.getsize(p) for p in HEADLINE) < 2 << 20
+                     "hpf_k20", "hpf_k64", "gauss_bias_k80", "gauss_bias_k112"}
+    assert sum(os.path.getsize(p) for p in HEADLINE) < 3 << 20
 
 
 @pytest.mark.parametrize("path", HEADLINE, ids=[os.path.basename(p)[:-4] for p in HEADLINE])

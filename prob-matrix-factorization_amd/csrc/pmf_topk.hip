@@ -252,6 +252,19 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int n
 // ties keep the lower item id.  With few query users the item range is cut into segments (gridDim.y) so
 // that the chip is filled; a merge kernel then picks the k best of the segments' lists.
 #define TOPK_NEG_INF (-__builtin_inff())
+#ifndef PRIO_SLICE
+#define PRIO_SLICE 16      // stages between priority rotations (tools/probe_topk_stamps.py sweeps it: 1 .. 64 are equivalent)
+#endif
+
+#ifdef PMF_TOPK_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/probe_topk_stamps.py compiles this file with -DPMF_TOPK_STAMPS into a library of its
+// own; the product library has no stamp): per (wavefront, user tile) the 100 MHz real-time stamps of the scan's begin
+// and end, the block's grid size and its XCC id -- the residency timeline of a launch.
+__device__ long long g_topk_stamps[16384 * 4];
+extern "C" int pmf_debug_topk_stamps(long long *host, int n_waves) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_topk_stamps), (size_t)n_waves * 4 * sizeof(long long));
+}
+#endif
 
 template <int KH>
 struct TopkStage {
@@ -272,8 +285,6 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, c = lane & 31;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
-    const bool active = q0 < p.nq;                     // a wave without users still stages item rows
     f32x4 *stage = reinterpret_cast<f32x4 *>(smem_raw);                                          // [2][ST][PQ]
     // [32][k] list entries of this wave's users, best first: (item id << 32) | score bits
     unsigned long long *le = reinterpret_cast<unsigned long long *>(smem_raw + S::bytes) + (size_t)wave * 32 * k;
@@ -281,6 +292,16 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     const int64_t i_begin = (int64_t)seg * seg_items;
     const int64_t i_end = i_begin + seg_items < p.n_items ? i_begin + seg_items : p.n_items;
     const int kpad = p.kpad;
+
+    // PERSISTENT blocks: the grid is sized to what the chip holds at once (launch_topk_fused_mode) and a block walks
+    // the 128-user tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int n_user_tiles = (p.nq + 127) / 128;
+    for (int ut = blockIdx.x; ut < n_user_tiles; ut += gridDim.x) {
+    const int q0 = (ut * 4 + wave) * 32;
+    const bool active = q0 < p.nq;                     // a wave without users still stages item rows
+#ifdef PMF_TOPK_STAMPS
+    const long long st_begin = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // A operand: this lane's pieces of user (q0 + c)'s row, resident for the whole scan
     const int user = (q0 + c < p.nq) ? p.users[q0 + c] : -1;
@@ -396,8 +417,22 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     fetch(i_begin);                                   // (segments are never empty)
     stash(0);
     __syncthreads();
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += ST) {
+    // Time-sliced priority.  Left alone, the SIMD's arbitration favours the same resident wave for a whole scan: the
+    // four blocks of a CU then finish one after the other (9.4 .. 16.5 ms for the same work) and the last quarter of
+    // the launch runs at 3, 2, 1 blocks per CU.  Rotating s_setprio over the SIMD's wave slots every PRIO_SLICE stages
+    // makes them finish together (12.3 .. 12.7 ms): profiles/r03_topk_wave_stamps.jsonl.
+    const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;   // HW_ID.WAVE_ID: this wave's slot on its SIMD
+    int stage_no = 0;
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += ST, ++stage_no) {
         const bool more = i0 + ST < i_end;
+        if ((stage_no & (PRIO_SLICE - 1)) == 0) {
+            switch ((slot + stage_no / PRIO_SLICE) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         if (more) fetch(i0 + ST);
         const f32x4 *rows = stage + (size_t)buf * ST * PQ;
         if (active) {
@@ -424,6 +459,19 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             cand_idx[((int64_t)qq * nseg + seg) * k + t] = idx;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lists are re-initialised for the next user tile
+    __builtin_amdgcn_wave_barrier();
+#ifdef PMF_TOPK_STAMPS
+    if (lane == 0 && seg == 0) {
+        long long *o = g_topk_stamps + (size_t)((ut * 4 + wave) & 16383) * 4;
+        o[0] = st_begin;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = gridDim.x;
+        o[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+    }
+#endif
+    }   // user tiles
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // k best of a user's nseg * k segment candidates, (value desc, item id asc); one wavefront per user
@@ -480,6 +528,17 @@ static hipError_t launch_topk_fused_mode(pmf_ctx *ctx, const TopkParams &p, dim3
         hipError_t e = hipFuncSetAttribute((const void *)topk_fused_kernel<KH, MODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
+    }
+    // persistent in x: at most as many blocks as are resident at once (the occupancy query x CUs), each walking its
+    // share of the 128-user tiles; with a segmented item range (few users) every (tile, segment) keeps its own block
+    if (grid.y == 1) {
+        int per_cu = 0, dev = 0, cus = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)topk_fused_kernel<KH, MODE>, 256, smem);
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        const unsigned resident = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
+        if (grid.x > resident) grid.x = resident;
     }
     hipLaunchKernelGGL((topk_fused_kernel<KH, MODE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
                        nseg, cand_val, cand_idx, out_items, out_scores);

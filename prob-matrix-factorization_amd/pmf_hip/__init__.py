@@ -121,6 +121,8 @@ def load():
     if _lib is not None:
         return _lib
     path = TEST_LIB_PATH if wants_test_library() else LIB_PATH
+    if os.environ.get("PMF_HIP_LIBRARY"):      # an explicit build of the same ABI (tools/: diagnostic builds with in-kernel stamps)
+        path = os.environ["PMF_HIP_LIBRARY"]
     if not os.path.exists(path):
         raise PmfLibraryError(
             f"{path} not found: the HIP engine has not been built. Run "

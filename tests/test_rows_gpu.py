@@ -100,3 +100,22 @@ def test_a_sweep_from_row_written_covariances_matches_numpy():
         V = np.linalg.inv(np.eye(K) / 0.5 + (V_beta[i[sel]].sum(axis=0) + mo.T @ mo) / 0.3)
         np.testing.assert_allclose(got_V[r], V, atol=1e-11)
         np.testing.assert_allclose(got_m[r], V @ (mo * x[sel][:, None]).sum(axis=0) / 0.3, atol=1e-11)
+
+
+def test_model_covariance_rows_equal_the_full_attribute():
+    """`V_theta_rows(ids)` / `V_beta_rows(ids)` read the packed device rows directly; the full attributes materialise the
+    whole (rows, K, K) stack -- same values, and asking for rows first must not materialise the stack."""
+    import pandas as pd
+    from src.models.gaussian_mf_cavi_bias import GaussianMFCAVI, GaussianMFCAVIConfig
+    rng = np.random.default_rng(2)
+    U, I, N, K = 400, 90, 6000, 12
+    df = pd.DataFrame({"u": rng.integers(0, U, N), "i": rng.integers(0, I, N), "rating": rng.normal(size=N)})
+    m = GaussianMFCAVI(GaussianMFCAVIConfig(n_factors=K, max_iter=2, tol=0.0, verbose=False), dtype="f64").fit(df)
+    uids, iids = rng.integers(0, m.n_users, 17), rng.integers(0, m.n_items, 9)
+    rows_u, rows_i = m.V_theta_rows(uids), m.V_beta_rows(iids)
+    assert m._V_theta is None and m._V_beta is None            # nothing was materialised
+    assert rows_u.shape == (17, K, K) and rows_i.shape == (9, K, K)
+    np.testing.assert_array_equal(rows_u, m.V_theta[uids])
+    np.testing.assert_array_equal(rows_i, m.V_beta[iids])
+    np.testing.assert_array_equal(m.V_theta_rows(uids), rows_u)  # (served from the materialised stack now)
+    m.close()

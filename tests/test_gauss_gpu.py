@@ -144,10 +144,10 @@ def test_half_sweeps_vs_oracle_skewed(K, dtype, tol):
 def test_mfma_kernel_matches_generic_kernel(K, monkeypatch):
     """The fp32 fast paths (K <= 64: one wavefront per task; 64 < K <= 128: two) (MFMA outer products, fused solve) against the
     generic accumulate kernel + standalone solve on the same inputs.  Above 64 also the un-fused launches
-    (PMF_GAUSS_UNFUSED: accumulate-only kernel + `gauss_solve_pair_kernel`), i.e. both homes of the two-wave solve: K = 79
-    is the RW = 40 row split's odd tail; 81 / 88 / 95 the RW = 48 split with a PARTIAL wave-1 phase (np1 < NP), an odd-K
-    tail step and the un-rotation of wave 1's registers in the epilogue (only K = 96, where wave 1 runs
-    all its pivot pairs, was covered)."""
+    (PMF_GAUSS_UNFUSED: accumulate-only kernel + `gauss_solve_pair_kernel`), i.e. both homes of the two-wave MFMA block
+    sweep: 5 tiles of 16 rows (K = 70, 79), 6 (81, 88, 95), 7 (100) and 8 (120, 128), with K not a multiple of 4 (a
+    pivot block that reaches into the identity padding: 70, 79, 81, 95) and not a multiple of 16 (ADVICE r2 asked for
+    K = 79 / 81 / 88 / 95 when these sizes still ran the VALU row splits)."""
     small = dict(N=20000) if K <= 64 else dict(N=7000, I=50, U=800)
     fast, _ = _oracle_vs_device(K, "f32", bias=True, iters=1, with_oracle=False, **small)
     unfused = None

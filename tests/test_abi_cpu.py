@@ -157,7 +157,13 @@ def test_hot_kernels_do_not_spill_and_use_the_intended_instructions(device_asm):
     assert body.count("v_mfma_f32_32x32x2_f32") >= 3
     assert body.count("global_load_dwordx4") >= 18          # two packed covariance rows per trip
     assert "v_readlane_b32" in body                          # the fused sweep solve
+    # 64 < K <= 128: the fused row solve runs on the 16x16x4 fp32 MFMA (rank-4 block sweep), 32 tiles per wave at K = 128
+    sym = re.search(r"^(_Z26gauss_accum_mfma128_kernelILi17ELb1ELi8E\S*):", gauss, re.M).group(1)
+    body = gauss[gauss.index(sym + ":"):]
+    body = body[:body.index("s_endpgm")]
+    assert body.count("v_mfma_f32_16x16x4_f32") >= 32 and body.count("v_mfma_f32_32x32x2_f32") >= 5
     assert "v_mfma_f32_32x32x2_f32" in device_asm["pmf_topk"]
+    assert "s_setprio" in device_asm["pmf_topk"]             # the time-sliced wave priority of the fused top-k scan
     gamma = device_asm["pmf_gamma"]
     assert "row_half_mirror" in gamma and "row_mirror" in gamma and "quad_perm" in gamma
     assert "global_atomic" not in gamma and "global_atomic" not in gauss   # deterministic: no atomics anywhere

@@ -328,15 +328,35 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     // Loads are unconditional (no branch, nothing for the loop's wait counters to merge): a row past the
     // segment's end re-reads the last row (its scores are never ranked), a piece past Kpad re-reads the
     // last piece (the A operand is zero there).
+    // (The scan is bound by the fp32 matrix pipe, and on gfx950 the fp32 MFMA shares the SIMD's fp32 lanes with the VALU:
+    //  every vector instruction of ANY resident wave costs the pipe its issue cycles -- profiles/r03_topk_wave_stamps.jsonl:
+    //  9.5 k cycles per tile for four waves whose MFMAs need 8.2 k.  Hence the running pointers here instead of 64-bit
+    //  row-address arithmetic per stage, and the scalar masks in the threshold test below.)
     f32x4 g[LPT];
     const int last_piece = kpad / 4 - 1;
-    auto fetch = [&](int64_t i0) __attribute__((always_inline)) {   // (out of line, g[] would live in scratch)
+    const char *gp[LPT];                              // this thread's pieces of the stage fetched next (full stages)
 #pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            const int idx = j * 256 + (int)threadIdx.x;
-            const int r = idx / PR, pc = idx % PR;
-            const int64_t it = i0 + r < i_end ? i0 + r : i_end - 1;
-            g[j] = *reinterpret_cast<const f32x4 *>(fi + it * kpad + 4 * (pc < last_piece ? pc : last_piece));
+    for (int j = 0; j < LPT; ++j) {
+        const int idx = j * 256 + (int)threadIdx.x;
+        const int r = idx / PR, pc = idx % PR;
+        gp[j] = reinterpret_cast<const char *>(fi + (i_begin + r) * kpad + 4 * (pc < last_piece ? pc : last_piece));
+    }
+    const int64_t stage_bytes = (int64_t)ST * kpad * 4;
+    auto fetch = [&](int64_t i0) __attribute__((always_inline)) {   // (out of line, g[] would live in scratch)
+        if (i0 + ST <= i_end) {                       // wave-uniform: every row of the stage exists
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                g[j] = *reinterpret_cast<const f32x4 *>(gp[j]);
+                gp[j] += stage_bytes;
+            }
+        } else {                                      // the segment's last, partial stage
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                const int idx = j * 256 + (int)threadIdx.x;
+                const int r = idx / PR, pc = idx % PR;
+                const int64_t it = i0 + r < i_end ? i0 + r : i_end - 1;
+                g[j] = *reinterpret_cast<const f32x4 *>(fi + it * kpad + 4 * (pc < last_piece ? pc : last_piece));
+            }
         }
     };
     auto stash = [&](int buf) __attribute__((always_inline)) {
@@ -385,28 +405,33 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         const bool ok = it < i_end;
         float ccst = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
         if (MODE != 0 && ok) ccst = ci[it];
-        bool any = false;
+        // the 16 threshold compares leave their lane masks in SGPRs (v_cmp -> s[..]); everything that follows until a
+        // candidate is actually inserted is scalar: no vector instruction competes with the other waves' MFMAs
+        unsigned long long mk[16], anym = 0ull;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float sc = acc[r];
             if (MODE == PMF_PREDICT_BIAS) sc = ucst[r] + ccst + sc;          // predict's order: b_u + b_i + dot
             if (MODE == PMF_PREDICT_SCALE) sc = sc * (ucst[r] * ccst);
             acc[r] = sc;
-            any |= ok && sc >= tau[r];
+            mk[r] = __builtin_amdgcn_ballot_w64(sc >= tau[r]);
+            anym |= mk[r];
         }
-        if (__ballot(any) == 0ull) return;
-        // rare: some score reaches its user's list.  Candidates go in ascending item order (lane order within
-        // the tile), so equal scores keep the lower item id in front.
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+        if ((anym & okm) == 0ull) return;
+        // some score reaches its user's list.  Candidates go in ascending item order (lane order within the tile), so
+        // equal scores keep the lower item id in front.
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            unsigned long long m = __ballot(ok && acc[r] >= tau[r]);
+            unsigned long long m = mk[r] & okm;
             while (m) {
                 const int L = __builtin_ctzll(m);
                 m &= m - 1;
                 const int hh = L >> 5;
                 const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (q0 + ul >= p.nq) continue;
-                const float v = __shfl(acc[r], L, 64);
+                const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[r]), L));
+                // (an earlier candidate of this tile may have raised the list's threshold past v: insert() re-checks)
                 const float nt = insert(ul, v, (int)(i0 + (L & 31)));
                 if (h == hh) tau[r] = nt;
             }

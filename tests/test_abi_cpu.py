@@ -108,8 +108,10 @@ def device_asm(tmp_path_factory):
     d = tmp_path_factory.mktemp("asm")
     for name in ("pmf_gamma", "pmf_gauss", "pmf_topk"):
         dst = d / f"{name}.s"
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize",
-                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"), "-S", "--cuda-device-only",
+        import __graft_entry__ as g
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize"] +
+                       g.EXTRA_FLAGS.get(f"{name}.hip", []) +
+                       ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"), "-S", "--cuda-device-only",
                         os.path.join(PKG, "csrc", f"{name}.hip"), "-o", str(dst)], check=True, capture_output=True)
         out[name] = dst.read_text()
     return out

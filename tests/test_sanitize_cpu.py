@@ -76,7 +76,8 @@ def test_host_side_under_address_and_ub_sanitizers(tmp_path):
         o = str(tmp_path / src.replace(".hip", ".o"))
         objs.append(o)
         procs.append(subprocess.Popen(
-            [hipcc, "-O1", "-g", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-result",
+            [hipcc, "-O1", "-g", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-result"] +
+            g.EXTRA_FLAGS.get(src, []) + [
              "-DPMF_TEST_TRANSPORT",     # the hostshm rehearsal transport is host code: it is sanitised with the rest
              "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
              "-Xarch_host", "-fno-sanitize-recover=undefined", "-Xarch_host", "-fno-omit-frame-pointer",

@@ -23,7 +23,7 @@ lib = os.path.join(work, "libpmf_hip_diag.so")
 #  and this process must load the diagnostic one instead)
 base = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-result",
         "-I", os.path.join(ROOT, "include"), "-I", g.CSRC]
-subprocess.run(base + ["-DPMF_TOPK_STAMPS"] + os.environ.get("PMF_DIAG_DEFS", "").split() + ["-c", os.path.join(g.CSRC, "pmf_topk.hip"), "-o", obj], check=True)
+subprocess.run(base + g.EXTRA_FLAGS.get("pmf_topk.hip", []) + ["-DPMF_TOPK_STAMPS"] + os.environ.get("PMF_DIAG_DEFS", "").split() + ["-c", os.path.join(g.CSRC, "pmf_topk.hip"), "-o", obj], check=True)
 objs = [obj if s == "pmf_topk.hip" else os.path.join(g.CSRC, "obj", s.replace(".hip", ".o")) for s in g.SOURCES]
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl"], check=True)
 os.environ["PMF_HIP_LIBRARY"] = lib

@@ -17,7 +17,11 @@ run() {  # name, program args...
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$name" -- python3 "$@" > "$O/$name.out" 2> "$O/$name.err" || { echo "FAILED $name"; tail -5 "$O/$name.err"; return 1; }
   tail -c 400 "$O/$name.out"; echo
 }
-STAGE="${1:-all}"    # trace | pmc | all (a gpurun call is limited to 20 minutes: run the two stages in separate calls)
+STAGE="${1:-all}"    # trace | pmc | all | topk (a gpurun call is limited to 20 minutes: run the stages in separate calls)
+if [ "$STAGE" = "topk" ]; then
+run topk          "$R/bench.py" --workload topk --steps 3 --warmup 1
+exit $?
+fi
 if [ "$STAGE" != "pmc" ]; then
 run gaussian_mf   "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --only &&
 run hpf_cavi      "$R/bench.py" --workload hpf_cavi --steps 10 --warmup 2 --no-cpu-baseline &&

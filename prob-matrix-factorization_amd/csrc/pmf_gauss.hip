@@ -349,20 +349,29 @@ __device__ __forceinline__ float rcp_nr(float x) {
 }
 
 // Precondition: img / wbuf are complete and the block has synchronised.  rt = PAIR_XBUF floats.
-template <int TT>
-__device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gbuf, const float *wbuf, int K, int kpad,
-                                                int cov_stride, float inv_sigma2, float inv_eta2, float *vout, float *mout,
-                                                int wave, int lane) {
+// W = the wavefront (0 / 1) as a compile-time constant: its tile rows are then known statically, the image build and the
+// packed write-back know for every tile whether it lies below, on or above the diagonal (no per-element compare; the
+// tiles above the diagonal are not written at all), and the two waves run their own copy of the code with the same
+// sequence of barriers.
+template <int TT, int W>
+__device__ __forceinline__ void pair_solve_mfma_wave(float *img, float *rt, float *gbuf, const float *wbuf, int K, int kpad,
+                                                     int cov_stride, float inv_sigma2, float inv_eta2, float *vout, float *mout,
+                                                     int lane) {
     constexpr int TH = (TT + 1) / 2;
+    constexpr int wave = W;
     const int tid = 64 * wave + lane;
     gbuf[tid] = 1.f / sqrtf(img[tid * (tid + 3) / 2] * inv_sigma2 + inv_eta2);   // (rows >= K: the padding diagonal gives 1)
     __syncthreads();
     const int lc = lane & 15, lg = lane >> 4;
-    const int base = wave ? TH : 0, nrows = wave ? TT - TH : TH;   // wave-uniform
+    constexpr int base = W ? TH : 0, nrows = W ? TT - TH : TH;
     f32x4 D[TH][TT];
     float gj[TT];
+    int tj[TT];                               // packed offset of this lane's column j as a ROW
 #pragma unroll
-    for (int J = 0; J < TT; ++J) gj[J] = gbuf[16 * J + lc];
+    for (int J = 0; J < TT; ++J) {
+        gj[J] = gbuf[16 * J + lc];
+        tj[J] = (16 * J + lc) * (16 * J + lc + 1) / 2;
+    }
 #pragma unroll
     for (int ii = 0; ii < TH; ++ii) {
         if (ii < nrows) {
@@ -374,8 +383,12 @@ __device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gb
 #pragma unroll
                 for (int J = 0; J < TT; ++J) {
                     const int j = 16 * J + lc;
-                    float v = img[i >= j ? ti + j : j * (j + 1) / 2 + i] * gi;
-                    if (i == j) v = fmaf(inv_eta2, gbuf[i], v);
+                    float v;
+                    if (base + ii > J) v = img[ti + j];                                  // a tile below the diagonal
+                    else if (base + ii < J) v = img[tj[J] + i];                          // above: the transposed entry
+                    else v = img[i >= j ? ti + j : tj[J] + i];
+                    v *= gi;
+                    if (base + ii == J && i == j) v = fmaf(inv_eta2, gbuf[i], v);
                     D[ii][J][r] = v * gj[J];
                 }
             }
@@ -488,7 +501,11 @@ __device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gb
                     const int j = 16 * J + lc;
                     const float b = D[ii][J][r] * gi;
                     acc = fmaf(b, xj[J], acc);
-                    if (j <= i && i < K) img[i * (i + 1) / 2 + j] = b * gj[J];
+                    if (base + ii > J) {                       // below the diagonal: every entry is stored
+                        if (i < K) img[i * (i + 1) / 2 + j] = b * gj[J];
+                    } else if (base + ii == J) {
+                        if (j <= i && i < K) img[i * (i + 1) / 2 + j] = b * gj[J];
+                    }
                 }
                 acc = group_sum<16>(acc);
                 if (lc == 0 && i < kpad) mout[i] = i < K ? acc * inv_sigma2 : 0.f;
@@ -498,6 +515,14 @@ __device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gb
     }
     __syncthreads();
     for (int qv = threadIdx.x * PMF_VEC; qv < cov_stride; qv += 128 * PMF_VEC) store4(vout + qv, load4(img + qv));
+}
+
+template <int TT>
+__device__ __forceinline__ void pair_solve_mfma(float *img, float *rt, float *gbuf, const float *wbuf, int K, int kpad,
+                                                int cov_stride, float inv_sigma2, float inv_eta2, float *vout, float *mout,
+                                                int wave, int lane) {
+    if (wave == 0) pair_solve_mfma_wave<TT, 0>(img, rt, gbuf, wbuf, K, kpad, cov_stride, inv_sigma2, inv_eta2, vout, mout, lane);
+    else pair_solve_mfma_wave<TT, 1>(img, rt, gbuf, wbuf, K, kpad, cov_stride, inv_sigma2, inv_eta2, vout, mout, lane);
 }
 
 template <int MT>

@@ -458,12 +458,22 @@ __device__ __forceinline__ void pair_solve_mfma_wave(float *img, float *rt, floa
             float a = -fmaf(x.w, dcol[3], fmaf(x.z, dcol[2], fmaf(x.y, dcol[1], x.x * dcol[0])));
             const bool prow = I == Ip;              // wave-uniform
             if (prow && piv) a = apiv;
+            // the accumulator entries of the pivot rows (tile row Ip) and pivot columns (tile column Ip) start from zero.
+            // Wave-uniform BRANCHES around the selects (the empty asm keeps the compiler from turning them back into
+            // selects on every tile): vector instructions take their issue cycles from the fp32 matrix pipe
+            if (prow) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int J = 0; J < TT; ++J)
+                    if (lg == qg) D[ii][J] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int J = 0; J < TT; ++J) {
-                f32x4 c = D[ii][J];
-                const bool zero = (prow && lg == qg) || (J == Ip && piv);
-                if (zero) c = f32x4{0.f, 0.f, 0.f, 0.f};
-                D[ii][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bop[J], c, 0, 0, 0);
+                if (J == Ip) {
+                    asm volatile("" ::: "memory");
+                    if (piv) D[ii][J] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                D[ii][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bop[J], D[ii][J], 0, 0, 0);
             }
         };
         // the tile row that holds the next pivots first, then its panel, then the rest

@@ -169,3 +169,40 @@ def test_hot_kernels_do_not_spill_and_use_the_intended_instructions(device_asm):
     gamma = device_asm["pmf_gamma"]
     assert "row_half_mirror" in gamma and "row_mirror" in gamma and "quad_perm" in gamma
     assert "global_atomic" not in gamma and "global_atomic" not in gauss   # deterministic: no atomics anywhere
+
+
+C_CLIENT = r'''
+#include <stdio.h>
+#include <string.h>
+#include "pmf_hip.h"
+/* a C99 client of the boundary: the header must compile as plain C and every prototype must link */
+int main(void) {
+    pmf_ctx *ctx = (pmf_ctx *)0x1;
+    int n = -1;
+    if (pmf_abi_version() != PMF_ABI_VERSION) return 10;
+    if (pmf_device_count(&n) == PMF_OK && n > 0) { puts("gpu present"); return 0; }
+    if (pmf_ctx_create(0, 10, 10, 8, PMF_F32, &ctx) >= 0 || ctx != NULL) return 11;      /* no GPU: an error code, out = NULL */
+    if (strlen(pmf_last_error()) == 0) return 12;
+    if (pmf_get_array_rows(NULL, PMF_SIDE_USER, PMF_ARR_COV, 0, NULL, NULL) != PMF_EINVAL) return 13;
+    if (pmf_comm_set_exchange(NULL, PMF_EXCHANGE_SCATTER_GATHER) != PMF_EINVAL) return 14;
+    if (pmf_ctx_destroy(NULL) != PMF_OK) return 15;
+    puts("c client ok");
+    return 0;
+}
+'''
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(built, tmp_path):
+    """The drop-in boundary is a C ABI: a C99 translation unit includes include/pmf_hip.h (-Wall -Wextra -Werror
+    -pedantic), links against libpmf_hip.so and gets error codes -- not crashes -- from a box without a GPU."""
+    src = tmp_path / "client.c"
+    src.write_text(C_CLIENT)
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(built.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe), "-L", libdir, "-lpmf_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib",
+                        "-Wl,--unresolved-symbols=ignore-in-shared-libs"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr[-2000:])
+    assert "c client ok" in out.stdout or "gpu present" in out.stdout

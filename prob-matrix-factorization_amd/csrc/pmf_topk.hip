@@ -266,28 +266,42 @@ extern "C" int pmf_debug_topk_stamps(long long *host, int n_waves) {
 }
 #endif
 
+// v_writelane_b32: (value, lane, old) -> old with `value` in lane `lane` (both wave-uniform).  This clang has no
+// __builtin for it; a declaration carrying the intrinsic's name binds to it.
+extern "C" __device__ int pmf_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane");
+
+// list keys of the fused kernel: score bits mapped so that unsigned order is the scores' order (0 = empty entry, below
+// every score); and back
+__device__ __forceinline__ unsigned topk_key_score_bits(unsigned hi) {   // (integer throughout: stays on the scalar unit)
+    const unsigned bits = (hi & 0x80000000u) ? hi ^ 0x80000000u : ~hi;
+    return hi == 0u ? 0xff800000u : bits;                                  // empty -> -inf
+}
+__device__ __forceinline__ float topk_key_score(unsigned hi) { return __uint_as_float(topk_key_score_bits(hi)); }
+
 template <int KH>
 struct TopkStage {
     static constexpr int ST = KH == 8 ? 64 : 32;      // item rows per stage (one MFMA tile; two where a tile is too short a load)
     static constexpr int PR = KH / 2;                 // 16-byte pieces per (padded) factor row
     static constexpr int PQ = PR + 1;                 // LDS row pitch in pieces; odd -> the 16 lanes of a b128 group hit 16 bank quads
     static constexpr int LPT = ST * PR / 256;         // pieces fetched per thread per stage
-    static constexpr size_t bytes = (size_t)2 * ST * PQ * 16;
+    static constexpr size_t buffer_bytes = (size_t)ST * PQ * 16;   // the kernel takes one or two of these (nbuf)
 };
 
 template <int KH, int MODE>
 __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const float *fu, const float *fi, const float *cu,
-                                                         const float *ci, int k, int64_t seg_items, int nseg,
+                                                         const float *ci, int k, int nbuf, int64_t seg_items, int nseg,
                                                          float *cand_val, int32_t *cand_idx, int32_t *out_items,
                                                          double *out_scores) {
     using S = TopkStage<KH>;
     constexpr int ST = S::ST, PR = S::PR, PQ = S::PQ, LPT = S::LPT;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (readfirstlane: the wave index is uniform, and the compiler only knows it once told -- what hangs off q0 then
+    //  branches on SCC instead of masking exec)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int h = lane >> 5, c = lane & 31;
-    f32x4 *stage = reinterpret_cast<f32x4 *>(smem_raw);                                          // [2][ST][PQ]
-    // [32][k] list entries of this wave's users, best first: (item id << 32) | score bits
-    unsigned long long *le = reinterpret_cast<unsigned long long *>(smem_raw + S::bytes) + (size_t)wave * 32 * k;
+    f32x4 *stage = reinterpret_cast<f32x4 *>(smem_raw);                                          // [nbuf][ST][PQ]
+    // [32][k] list entries of this wave's users, best first: 64-bit keys (insert() below)
+    unsigned long long *le = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * S::buffer_bytes) + (size_t)wave * 32 * k;
     const int seg = blockIdx.y;
     const int64_t i_begin = (int64_t)seg * seg_items;
     const int64_t i_end = i_begin + seg_items < p.n_items ? i_begin + seg_items : p.n_items;
@@ -322,8 +336,7 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         ucst[r] = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
         if (MODE != 0 && qq < p.nq) ucst[r] = cu[p.users[qq]];
     }
-    const unsigned long long empty = ((unsigned long long)0x7fffffffu << 32) | __float_as_uint(TOPK_NEG_INF);
-    for (int e = lane; e < 32 * k; e += 64) le[e] = empty;
+    for (int e = lane; e < 32 * k; e += 64) le[e] = 0ull;   // empty entries: the key below every score's
 
     // Loads are unconditional (no branch, nothing for the loop's wait counters to merge): a row past the
     // segment's end re-reads the last row (its scores are never ranked), a piece past Kpad re-reads the
@@ -366,30 +379,50 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             stage[(size_t)buf * ST * PQ + (idx / PR) * PQ + idx % PR] = g[j];
         }
     };
-    // insert (v, item) into the list of local user `ul`; returns that list's new k-th best value
-    auto insert = [&](int ul, float v, int item) -> float {
+    // insert (v, item) into the list of local user `ul`; returns that list's new k-th best value (its bits).  Lane e holds entry e.
+    // An entry is one 64-bit key, (score bits made monotone) << 32 | ~item: a bigger key ranks first, so the candidate's
+    // place is ONE 64-bit compare and a ballot, its key is built with scalar instructions and dropped into its lane with
+    // v_writelane, and the entries behind it move down one lane (DPP).  Nine vector instructions and one LDS round trip --
+    // the (score, item) pair compare this replaces took about 25, and the vector ALU's cycles are the matrix pipe's.
+    const unsigned long long kmask = k >= 64 ? ~0ull : (1ull << k) - 1;   // the lanes that hold list entries
+    auto insert = [&](int ul, float v, int item) __attribute__((always_inline)) -> unsigned {
+        unsigned vb = __float_as_uint(v);
+        if (vb == 0x80000000u) vb = 0u;                              // -0.0 ranks as +0.0 does
+        const unsigned ov = vb ^ ((unsigned)((int)vb >> 31) | 0x80000000u);
+        const unsigned nitem = ~(unsigned)item;
+        const unsigned long long ck = ((unsigned long long)ov << 32) | nitem;
         unsigned long long *ue = le + ul * k;
-        const bool mine = lane < k;
-        const unsigned long long e = mine ? ue[lane] : 0ull;
-        const float ev = __uint_as_float((unsigned)e);
-        const int ei = (int)(e >> 32);
-        const bool before = mine && (ev > v || (ev == v && ei < item));
-        const int pos = __popcll(__ballot(before));          // entries that rank before the candidate
-        // entry of the lane below (wave_shr:1; lane 0 is never shifted into: it is either before or at pos)
-        const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)(unsigned)e, 0x138, 0xf, 0xf, false));
-        const int pi = __builtin_amdgcn_update_dpp(0, ei, 0x138, 0xf, 0xf, false);
-        float nv = ev;
-        int ni = ei;
-        if (lane == pos) { nv = v; ni = item; }
-        else if (lane > pos) { nv = pv; ni = pi; }
-        if (mine && pos < k) ue[lane] = ((unsigned long long)(unsigned)ni << 32) | __float_as_uint(nv);
+        // (every lane reads: past entry k - 1 it is the next lists' entries, or the padding behind the last one; they are
+        //  masked out of the ballot and never written back -- no divergent region, the k-th entry is read as a scalar)
+        const unsigned long long e = ue[lane];
+        unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
+        const int pos = __popcll(__builtin_amdgcn_ballot_w64(e > ck) & kmask);   // entries that rank before the candidate
+        if (pos < k) {                                               // (an earlier candidate of this tile may have filled the list)
+            // the entries from `pos` on move down one lane: EXEC is cut to those lanes with scalar instructions and the
+            // DPP moves run in place (lane pos has no active source and keeps its entry until the writelane).  A lane
+            // compare and two selects would do the same with three more vector instructions.
+            const unsigned long long from = ~0ull << pos;
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[from]\n\t"
+                         "s_nop 4\n\t"
+                         "v_mov_b32_dpp %[lo], %[lo] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_mov_b32_dpp %[hi], %[hi] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [lo] "+v"(lo), [hi] "+v"(hi), [sv] "=&s"(saved)
+                         : [from] "s"(from));
+            lo = (unsigned)pmf_writelane((int)nitem, pos, (int)lo);
+            hi = (unsigned)pmf_writelane((int)ov, pos, (int)hi);
+            if (lane < k) ue[lane] = ((unsigned long long)hi << 32) | lo;
+        }
+        const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)hi, k - 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pos < k ? nv : ev), k - 1));
+        return topk_key_score_bits(kth);
     };
 
-    auto tile = [&](int64_t i0, const f32x4 *rows) {
-        f32x16 acc;
+    // the KH MFMA steps of one 32-item tile, B operand from the staged rows
+    auto mfma_all = [&](const f32x4 *rows, f32x16 &acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const f32x4 *mine = rows + c * PQ + h;
@@ -401,13 +434,17 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b.w, acc, 0, 0, 0);
         }
+    };
+    // dot products -> scores; the 16 threshold compares leave their lane masks in SGPRs (v_cmp -> s[..]): everything
+    // that follows until a candidate is actually inserted is scalar, no vector instruction competes with the other
+    // waves' MFMAs.  Returns whether any score of an existing item reaches its user's list.
+    auto thresholds = [&](int64_t i0, f32x16 &acc, unsigned long long (&mk)[16], unsigned long long &okm)
+                          __attribute__((always_inline)) -> bool {
         const int64_t it = i0 + c;
         const bool ok = it < i_end;
         float ccst = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
         if (MODE != 0 && ok) ccst = ci[it];
-        // the 16 threshold compares leave their lane masks in SGPRs (v_cmp -> s[..]); everything that follows until a
-        // candidate is actually inserted is scalar: no vector instruction competes with the other waves' MFMAs
-        unsigned long long mk[16], anym = 0ull;
+        unsigned long long anym = 0ull;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float sc = acc[r];
@@ -417,10 +454,13 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             mk[r] = __builtin_amdgcn_ballot_w64(sc >= tau[r]);
             anym |= mk[r];
         }
-        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
-        if ((anym & okm) == 0ull) return;
-        // some score reaches its user's list.  Candidates go in ascending item order (lane order within the tile), so
-        // equal scores keep the lower item id in front.
+        okm = __builtin_amdgcn_ballot_w64(ok);
+        return (anym & okm) != 0ull;
+    };
+    // the tile's candidates go into their lists in ascending item order (lane order within the tile), so equal scores
+    // keep the lower item id in front
+    auto drain = [&](int64_t i0, const f32x16 &acc, const unsigned long long (&mk)[16], unsigned long long okm)
+                     __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             unsigned long long m = mk[r] & okm;
@@ -432,24 +472,31 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
                 if (q0 + ul >= p.nq) continue;
                 const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[r]), L));
                 // (an earlier candidate of this tile may have raised the list's threshold past v: insert() re-checks)
-                const float nt = insert(ul, v, (int)(i0 + (L & 31)));
-                if (h == hh) tau[r] = nt;
+                const unsigned nt = insert(ul, v, (int)(i0 + (L & 31)));
+                // tau[r] = nt in the half-wave (h == hh) that holds this user's row: one v_mov under a scalar EXEC
+                const unsigned long long half = 0xffffffffull << (32 * hh);
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b64 exec, %[half]\n\t"
+                             "v_mov_b32 %[t], %[nt]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [t] "+v"(tau[r]), [sv] "=&s"(saved)
+                             : [half] "s"(half), [nt] "s"(nt));
             }
         }
     };
-    // every wave of the block runs the same number of stages (the barriers below)
-    int buf = 0;
-    fetch(i_begin);                                   // (segments are never empty)
-    stash(0);
-    __syncthreads();
+    auto tile = [&](int64_t i0, const f32x4 *rows) __attribute__((always_inline)) {
+        f32x16 acc;
+        unsigned long long mk[16], okm;
+        mfma_all(rows, acc);
+        if (thresholds(i0, acc, mk, okm)) drain(i0, acc, mk, okm);
+    };
     // Time-sliced priority.  Left alone, the SIMD's arbitration favours the same resident wave for a whole scan: the
     // four blocks of a CU then finish one after the other (9.4 .. 16.5 ms for the same work) and the last quarter of
     // the launch runs at 3, 2, 1 blocks per CU.  Rotating s_setprio over the SIMD's wave slots every PRIO_SLICE stages
     // makes them finish together (12.3 .. 12.7 ms): profiles/r03_topk_wave_stamps.jsonl.
     const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;   // HW_ID.WAVE_ID: this wave's slot on its SIMD
-    int stage_no = 0;
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += ST, ++stage_no) {
-        const bool more = i0 + ST < i_end;
+    auto rotate_priority = [&](int stage_no) __attribute__((always_inline)) {
         if ((stage_no & (PRIO_SLICE - 1)) == 0) {
             switch ((slot + stage_no / PRIO_SLICE) & 3) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -458,15 +505,32 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
         }
-        if (more) fetch(i0 + ST);
-        const f32x4 *rows = stage + (size_t)buf * ST * PQ;
-        if (active) {
-            tile(i0, rows);
-            if (ST == 64 && i0 + 32 < i_end) tile(i0 + 32, rows + 32 * PQ);
+    };
+    // every wave of the block runs the same number of stages (the barriers below)
+    int buf = 0, stage_no = 0;
+    fetch(i_begin);                                   // (segments are never empty)
+    stash(0);
+    __syncthreads();
+    {
+        for (int64_t i0 = i_begin; i0 < i_end; i0 += ST, ++stage_no) {
+            const bool more = i0 + ST < i_end;
+            rotate_priority(stage_no);
+            if (more) fetch(i0 + ST);
+            const f32x4 *rows = stage + (size_t)buf * ST * PQ;
+            if (active) {
+                tile(i0, rows);
+                if (ST == 64 && i0 + 32 < i_end) tile(i0 + 32, rows + 32 * PQ);
+            }
+            if (nbuf == 2) {
+                if (more) stash(buf ^ 1);             // last read there: the stage before this one, behind the barrier
+                __syncthreads();
+                buf ^= 1;
+            } else {                                  // one buffer (long lists: the LDS saved keeps another block resident)
+                __syncthreads();                      // every wave has read this stage
+                if (more) stash(0);
+                __syncthreads();
+            }
         }
-        if (more) stash(buf ^ 1);                     // last read there: the stage before this one, behind the barrier
-        __syncthreads();
-        buf ^= 1;
     }
     // hand the lists over: final result when the item range was not segmented, else this segment's candidates
     for (int e = lane; e < 32 * k; e += 64) {
@@ -474,8 +538,8 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         const int qq = q0 + ul;
         if (qq >= p.nq) continue;
         const unsigned long long ent = le[e];
-        const float v = __uint_as_float((unsigned)ent);
-        const int idx = (int)(ent >> 32);
+        const float v = topk_key_score((unsigned)(ent >> 32));
+        const int idx = ent == 0ull ? 0x7fffffff : (int)~(unsigned)ent;
         if (nseg == 1) {
             out_items[(int64_t)qq * k + t] = idx == 0x7fffffff ? -1 : idx;
             out_scores[(int64_t)qq * k + t] = idx == 0x7fffffff ? 0.0 : (double)v;
@@ -548,25 +612,33 @@ static hipError_t launch_topk_fused_mode(pmf_ctx *ctx, const TopkParams &p, dim3
                                          const float *fi, const float *cu, const float *ci, int k, int64_t seg_items,
                                          int nseg, float *cand_val, int32_t *cand_idx, int32_t *out_items,
                                          double *out_scores) {
-    const size_t smem = TopkStage<KH>::bytes + list_bytes;
-    if (smem > (64u << 10)) {   // two stage buffers + long lists (k > ~30 at K > 64): past the default dynamic-LDS limit
-        hipError_t e = hipFuncSetAttribute((const void *)topk_fused_kernel<KH, MODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    // One stage buffer or two.  Two (one barrier per stage) is the faster loop at equal residency, but the lists take
+    // 1 KB of LDS per k and block: from k = 23 at K = 64 the second buffer costs the CU a resident block
+    // (profiles/r03_topk_long_lists.jsonl: 34.3 -> 30.8 ms at k = 24, 72.9 -> 49.3 ms at k = 64).  Take one buffer where
+    // it keeps more blocks on the CU.  (ctx->topk_stage_buffers pins it: PMF_TOPK_STAGE_BUFFERS, for the probes.)
+    const void *fn = (const void *)topk_fused_kernel<KH, MODE>;
+    const size_t smem2 = 2 * TopkStage<KH>::buffer_bytes + list_bytes, smem1 = TopkStage<KH>::buffer_bytes + list_bytes;
+    if (smem2 > (64u << 10)) {   // long lists at K > 64: past the default dynamic-LDS limit
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         if (e != hipSuccess) return e;
     }
+    int per_cu2 = 0, per_cu1 = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, fn, 256, smem2);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, fn, 256, smem1);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    int nbuf = per_cu1 > per_cu2 ? 1 : 2;
+    if (ctx->topk_stage_buffers == 1 || ctx->topk_stage_buffers == 2) nbuf = ctx->topk_stage_buffers;
+    const size_t smem = nbuf == 2 ? smem2 : smem1;
     // persistent in x: at most as many blocks as are resident at once (the occupancy query x CUs), each walking its
     // share of the 128-user tiles; with a segmented item range (few users) every (tile, segment) keeps its own block
     if (grid.y == 1) {
-        int per_cu = 0, dev = 0, cus = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)topk_fused_kernel<KH, MODE>, 256, smem);
-        if (e == hipSuccess) e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-        const unsigned resident = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
+        const unsigned resident = (unsigned)std::max(1, nbuf == 2 ? per_cu2 : per_cu1) * (unsigned)std::max(1, cus);
         if (grid.x > resident) grid.x = resident;
     }
-    hipLaunchKernelGGL((topk_fused_kernel<KH, MODE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
-                       nseg, cand_val, cand_idx, out_items, out_scores);
+    hipLaunchKernelGGL((topk_fused_kernel<KH, MODE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, nbuf,
+                       seg_items, nseg, cand_val, cand_idx, out_items, out_scores);
     return hipSuccess;
 }
 
@@ -610,7 +682,7 @@ static int run_topk_fused(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids
     int32_t *d_users = (int32_t *)(base + out_s + out_i);
     float *d_cv = (float *)(base + out_s + out_i + id_bytes);
     int32_t *d_ci = (int32_t *)(base + out_s + out_i + id_bytes + cv_bytes);
-    const size_t list_bytes = (size_t)8 * 32 * k * sizeof(float);
+    const size_t list_bytes = (size_t)8 * 32 * k * sizeof(float) + 512;   // + 64 entries: insert() reads a full wave's width
     for (int64_t at = 0; at < n_query; at += Q) {
         const int nq = (int)std::min<int64_t>(Q, n_query - at);
         PMF_HIP_CHECK(hipMemcpyAsync(d_users, user_ids + at, (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));

@@ -106,21 +106,30 @@ def test_fp32_engine_gives_the_reference_top10(case):
     assert exact.mean() > 0.97
 
 
-@pytest.mark.parametrize("K,k,mode", [(64, 10, 0), (64, 64, 1), (128, 10, 2), (20, 7, 1), (12, 33, 0),
-                                       (100, 64, 1)])   # last: stage buffers + 64-entry lists > 64 KB of LDS
-def test_fused_topk_equals_the_two_phase_path(K, k, mode, monkeypatch):
+@pytest.mark.parametrize("K,k,mode,signed", [(64, 10, 0, False), (64, 64, 1, False), (128, 10, 2, False), (20, 7, 1, False),
+                                              (12, 33, 0, False),
+                                              (100, 64, 1, False),   # stage buffers + 64-entry lists > 64 KB of LDS
+                                              (64, 10, 0, True), (32, 50, 1, True), (128, 24, 0, True)])
+def test_fused_topk_equals_the_two_phase_path(K, k, mode, signed, monkeypatch):
     """The fused kernel (MFMA score tiles + running k best in LDS, item range cut into segments and merged) against
     the two-phase path (score matrix in HBM, then select): same items, scores equal up to the summation order
-    of the two kernels; exact ties and a NaN row included."""
+    of the two kernels; exact ties and a NaN row included.  `signed`: Gaussian factors, so scores of both signs -- the
+    lists are kept as integer keys whose order must be the floats' -- and, for the all-zero user, zeros of both signs
+    (0 * -x = -0.0), which rank as equal."""
     import pmf_hip
     from pmf_hip import ARR_BIAS, ARR_FACTOR, ARR_SCALE, ITEM, USER
     rng = np.random.default_rng(K + k)
     U, I = 700, 20011                       # not multiples of 32; 20011 items -> several segments
-    A, B = rng.gamma(0.5, 1.0, (U, K)), rng.gamma(0.5, 1.0, (I, K))
+    if signed:
+        A, B = rng.standard_normal((U, K)), rng.standard_normal((I, K))
+    else:
+        A, B = rng.gamma(0.5, 1.0, (U, K)), rng.gamma(0.5, 1.0, (I, K))
     B[I - 1] = B[11]; B[4000] = B[11]       # exact ties across segments
     B[77] = np.nan                          # an item whose scores are NaN never ranks
     A[5] = 0.0                              # a user whose scores are all equal (0): k lowest item ids win
     cu, ci = rng.gamma(1.0, 1.0, U) + 0.1, rng.gamma(1.0, 1.0, I) + 0.1
+    if signed:
+        cu, ci = rng.standard_normal(U), rng.standard_normal(I)
     ci[I - 1] = ci[4000] = ci[11]
     users = rng.permutation(U)[:333]
     users[0] = 5

@@ -2,7 +2,9 @@
 K = 64, k = 10) on two item tables: random factors (about 92 list changes per user over the scan, i.e. about every
 third 32-item tile of a wave finds a candidate) and factors scaled so that every user's scores DESCEND with the item
 id (all list changes happen in the first tile; every later tile ends at the threshold compare).
-    python tools/probe_topk_inserts.py"""
+    python tools/probe_topk_inserts.py [--k 1 10 50] [--buffers 0 [1 2]] [--random-only]
+--buffers pins the kernel's stage buffering per run (PMF_TOPK_STAGE_BUFFERS; 0 = the library's own choice)."""
+import argparse
 import json
 import os
 import sys
@@ -14,13 +16,22 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "prob-matrix-factorization_amd")]
 import pmf_hip  # noqa: E402
 from pmf_hip import ARR_FACTOR, ITEM, USER  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--k", type=int, nargs="+", default=[1, 10, 50])
+ap.add_argument("--buffers", type=int, nargs="+", default=[0])
+ap.add_argument("--random-only", action="store_true")
+args = ap.parse_args()
 U, I, K, Q = 1_000_000, 100_000, 64, 262_144
 rng = np.random.default_rng(0)
 users = rng.permutation(U)[:Q].astype(np.int32)
 theta = rng.gamma(0.5, 1.0, (U, K))
 for label, beta in (("random item factors", rng.gamma(0.5, 1.0, (I, K))),
-                    ("scores descending with the item id", np.outer(np.linspace(2.0, 1.0, I), np.ones(K)))):
-    for k in (1, 10, 50):
+                    ("scores descending with the item id", np.outer(np.linspace(2.0, 1.0, I), np.ones(K))))[:1 if args.random_only else 2]:
+  for k in args.k:
+    for nb in args.buffers:
+        os.environ.pop("PMF_TOPK_STAGE_BUFFERS", None)
+        if nb:
+            os.environ["PMF_TOPK_STAGE_BUFFERS"] = str(nb)         # read when the context is created
         with pmf_hip.Context(U, I, K, dtype="f32") as ctx:
             ctx.set_array(USER, ARR_FACTOR, theta)
             ctx.set_array(ITEM, ARR_FACTOR, beta)
@@ -31,5 +42,5 @@ for label, beta in (("random item factors", rng.gamma(0.5, 1.0, (I, K))),
                 ctx.topk_items(users, k)
             ms, n = ctx.prof_get()["topk"]
         tf = 2.0 * Q * I * K / (ms / n * 1e-3) / 1e12
-        print(json.dumps({"items": label, "k": k, "kernel_ms": round(ms / n, 3), "TFLOP/s": round(tf, 1),
+        print(json.dumps({"items": label, "k": k, "stage_buffers": nb or "auto", "kernel_ms": round(ms / n, 3), "TFLOP/s": round(tf, 1),
                           "frac_of_157.3": round(tf / 157.3, 3)}), flush=True)

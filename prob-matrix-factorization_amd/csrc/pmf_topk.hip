@@ -259,10 +259,11 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const S *scores, int n
 #ifdef PMF_TOPK_STAMPS
 // DIAGNOSTIC BUILD ONLY (tools/probe_topk_stamps.py compiles this file with -DPMF_TOPK_STAMPS into a library of its
 // own; the product library has no stamp): per (wavefront, user tile) the 100 MHz real-time stamps of the scan's begin
-// and end, the block's grid size and its XCC id -- the residency timeline of a launch.
-__device__ long long g_topk_stamps[16384 * 4];
+// and end, the block's grid size and its XCC id -- the residency timeline of a launch -- and the shader-clock cycles
+// the wave spent ranking candidates and waiting at the stage barriers, with the number of candidates.
+__device__ long long g_topk_stamps[16384 * 8];
 extern "C" int pmf_debug_topk_stamps(long long *host, int n_waves) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_topk_stamps), (size_t)n_waves * 4 * sizeof(long long));
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_topk_stamps), (size_t)n_waves * 8 * sizeof(long long));
 }
 #endif
 
@@ -315,6 +316,10 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     const bool active = q0 < p.nq;                     // a wave without users still stages item rows
 #ifdef PMF_TOPK_STAMPS
     const long long st_begin = __builtin_amdgcn_s_memrealtime();
+    long long st_drain = 0, st_barrier = 0, st_cand = 0, st_tiles = 0;
+#define STAMP_BARRIER() do { const long long t_ = __builtin_amdgcn_s_memtime(); __syncthreads(); st_barrier += __builtin_amdgcn_s_memtime() - t_; } while (0)
+#else
+#define STAMP_BARRIER() __syncthreads()
 #endif
 
     // A operand: this lane's pieces of user (q0 + c)'s row, resident for the whole scan
@@ -485,25 +490,42 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             }
         }
     };
-    auto tile = [&](int64_t i0, const f32x4 *rows) __attribute__((always_inline)) {
-        f32x16 acc;
-        unsigned long long mk[16], okm;
-        mfma_all(rows, acc);
-        if (thresholds(i0, acc, mk, okm)) drain(i0, acc, mk, okm);
-    };
     // Time-sliced priority.  Left alone, the SIMD's arbitration favours the same resident wave for a whole scan: the
     // four blocks of a CU then finish one after the other (9.4 .. 16.5 ms for the same work) and the last quarter of
     // the launch runs at 3, 2, 1 blocks per CU.  Rotating s_setprio over the SIMD's wave slots every PRIO_SLICE stages
     // makes them finish together (12.3 .. 12.7 ms): profiles/r03_topk_wave_stamps.jsonl.
     const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;   // HW_ID.WAVE_ID: this wave's slot on its SIMD
+    auto slice_priority = [&](int stage_no) __attribute__((always_inline)) {
+        switch ((slot + stage_no / PRIO_SLICE) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
     auto rotate_priority = [&](int stage_no) __attribute__((always_inline)) {
-        if ((stage_no & (PRIO_SLICE - 1)) == 0) {
-            switch ((slot + stage_no / PRIO_SLICE) & 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
+        if ((stage_no & (PRIO_SLICE - 1)) == 0) slice_priority(stage_no);
+    };
+    auto tile = [&](int64_t i0, const f32x4 *rows, int stage_no) __attribute__((always_inline)) {
+        f32x16 acc;
+        unsigned long long mk[16], okm;
+        mfma_all(rows, acc);
+        if (thresholds(i0, acc, mk, okm)) {
+#ifdef PMF_TOPK_STAMPS
+            const long long t_ = __builtin_amdgcn_s_memtime();
+            for (int r = 0; r < 16; ++r) st_cand += __builtin_popcountll(mk[r] & okm);
+            ++st_tiles;
+#endif
+#ifdef PMF_TOPK_RANK_PRIORITY   // (experiment: rank at the top priority, then step back to the time slice's -- no gain)
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            drain(i0, acc, mk, okm);
+#ifdef PMF_TOPK_RANK_PRIORITY
+            slice_priority(stage_no);
+#endif
+#ifdef PMF_TOPK_STAMPS
+            st_drain += __builtin_amdgcn_s_memtime() - t_;
+#endif
         }
     };
     // every wave of the block runs the same number of stages (the barriers below)
@@ -518,17 +540,17 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             if (more) fetch(i0 + ST);
             const f32x4 *rows = stage + (size_t)buf * ST * PQ;
             if (active) {
-                tile(i0, rows);
-                if (ST == 64 && i0 + 32 < i_end) tile(i0 + 32, rows + 32 * PQ);
+                tile(i0, rows, stage_no);
+                if (ST == 64 && i0 + 32 < i_end) tile(i0 + 32, rows + 32 * PQ, stage_no);
             }
             if (nbuf == 2) {
                 if (more) stash(buf ^ 1);             // last read there: the stage before this one, behind the barrier
-                __syncthreads();
+                STAMP_BARRIER();
                 buf ^= 1;
             } else {                                  // one buffer (long lists: the LDS saved keeps another block resident)
-                __syncthreads();                      // every wave has read this stage
+                STAMP_BARRIER();                      // every wave has read this stage
                 if (more) stash(0);
-                __syncthreads();
+                STAMP_BARRIER();
             }
         }
     }
@@ -552,11 +574,15 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     __builtin_amdgcn_wave_barrier();
 #ifdef PMF_TOPK_STAMPS
     if (lane == 0 && seg == 0) {
-        long long *o = g_topk_stamps + (size_t)((ut * 4 + wave) & 16383) * 4;
+        long long *o = g_topk_stamps + (size_t)((ut * 4 + wave) & 16383) * 8;
         o[0] = st_begin;
         o[1] = __builtin_amdgcn_s_memrealtime();
         o[2] = gridDim.x;
         o[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+        o[4] = st_drain;
+        o[5] = st_barrier;
+        o[6] = st_cand;
+        o[7] = st_tiles;
     }
 #endif
     }   // user tiles

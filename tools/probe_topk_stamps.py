@@ -48,9 +48,9 @@ for label, beta in (("random item factors", rng.gamma(0.5, 1.0, (I, K))),
         ctx.topk_items(users, k)
         ms, n = ctx.prof_get()["topk"]
         n_waves = Q // 32
-        raw = np.zeros(n_waves * 4, dtype=np.int64)
+        raw = np.zeros(n_waves * 8, dtype=np.int64)
         assert L.pmf_debug_topk_stamps(raw.ctypes.data, n_waves) == 0
-        raw = raw.reshape(-1, 4)
+        raw = raw.reshape(-1, 8)
         t0 = raw[:, 0].min()
         begin, end = (raw[:, 0] - t0) / 100.0, (raw[:, 1] - t0) / 100.0          # microseconds
         grid = np.linspace(0, end.max(), 41)
@@ -58,4 +58,10 @@ for label, beta in (("random item factors", rng.gamma(0.5, 1.0, (I, K))),
         print(json.dumps({"items": label, "k": k, "kernel_ms": round(ms / n, 3), "grid_x": int(raw[0, 2]),
                           "waves_in_their_scan_at_41_instants": alive, "span_us": round(float(end.max()), 1),
                           "scan_us_per_user_tile_median": round(float(np.median(end - begin)), 1),
-                          "scan_us_per_user_tile_p5_p95": [round(float(np.percentile(end - begin, 5)), 1), round(float(np.percentile(end - begin, 95)), 1)]}), flush=True)
+                          "scan_us_per_user_tile_p5_p95": [round(float(np.percentile(end - begin, 5)), 1), round(float(np.percentile(end - begin, 95)), 1)],
+                          # shader-clock cycles per wave and scan (3125 tiles), means over the wavefronts
+                          "cycles_ranking_candidates_mean": round(float(raw[:, 4].mean())),
+                          "cycles_at_stage_barriers_mean": round(float(raw[:, 5].mean())),
+                          "candidates_per_wave_scan_mean": round(float(raw[:, 6].mean()), 1),
+                          "tiles_with_candidates_mean": round(float(raw[:, 7].mean()), 1),
+                          "scan_cycles_at_2.39GHz_median": round(float(np.median(end - begin)) * 2390)}), flush=True)

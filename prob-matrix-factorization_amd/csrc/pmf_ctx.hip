@@ -185,6 +185,7 @@ extern "C" int pmf_ctx_create(int device, int64_t n_users, int64_t n_items, int 
     ctx->gauss_lds_solve = getenv("PMF_GAUSS_LDS_SOLVE") != nullptr;
     ctx->topk_two_phase = getenv("PMF_TOPK_TWO_PHASE") != nullptr;
     if (const char *nb = getenv("PMF_TOPK_STAGE_BUFFERS")) ctx->topk_stage_buffers = atoi(nb);
+    if (const char *mb = getenv("PMF_TOPK_MAX_BLOCKS")) ctx->topk_max_blocks = atoi(mb);
     if (const char *ex = getenv("PMF_COMM_EXCHANGE")) {
         if (!strcmp(ex, "allreduce")) ctx->exchange = PMF_EXCHANGE_ALLREDUCE;
         else if (!strcmp(ex, "scatter_gather")) ctx->exchange = PMF_EXCHANGE_SCATTER_GATHER;

@@ -146,6 +146,7 @@ struct pmf_ctx {
     bool gauss_generic = false;    // PMF_GAUSS_GENERIC: the generic accumulate kernel instead of the MFMA ones
     bool gauss_unfused = false;    // PMF_GAUSS_UNFUSED: accumulate and solve as separate launches
     bool gauss_lds_solve = false;  // PMF_GAUSS_LDS_SOLVE: the block-per-row LDS solve for 64 < K <= 128
+    int topk_max_blocks = 0;       // PMF_TOPK_MAX_BLOCKS=n caps the fused kernel's persistent grid (tests: many tiles per block)
     int topk_stage_buffers = 0;    // PMF_TOPK_STAGE_BUFFERS=1|2 pins the fused kernel's stage buffering (0: by residency)
     bool topk_two_phase = false;   // PMF_TOPK_TWO_PHASE: score matrix in HBM + select instead of the fused kernel
 

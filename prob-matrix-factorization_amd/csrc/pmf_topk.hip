@@ -271,11 +271,12 @@ extern "C" int pmf_debug_topk_stamps(long long *host, int n_waves) {
 // __builtin for it; a declaration carrying the intrinsic's name binds to it.
 extern "C" __device__ int pmf_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane");
 
-// list keys of the fused kernel: score bits mapped so that unsigned order is the scores' order (0 = empty entry, below
-// every score); and back
+// list keys of the fused kernel: (score bits mapped so that unsigned order is the scores' order) << 32 | ~item.  An empty
+// entry is -inf's key with a zero low word: below every candidate's key (no item id has ~item == 0), and its score
+// reads back as -inf without a special case.
+#define TOPK_EMPTY_KEY 0x007fffff00000000ull
 __device__ __forceinline__ unsigned topk_key_score_bits(unsigned hi) {   // (integer throughout: stays on the scalar unit)
-    const unsigned bits = (hi & 0x80000000u) ? hi ^ 0x80000000u : ~hi;
-    return hi == 0u ? 0xff800000u : bits;                                  // empty -> -inf
+    return hi ^ ((int)hi < 0 ? 0x80000000u : 0xffffffffu);
 }
 __device__ __forceinline__ float topk_key_score(unsigned hi) { return __uint_as_float(topk_key_score_bits(hi)); }
 
@@ -288,8 +289,10 @@ struct TopkStage {
     static constexpr size_t buffer_bytes = (size_t)ST * PQ * 16;   // the kernel takes one or two of these (nbuf)
 };
 
+// (waves per SIMD the register allocation must leave room for: four for the plain K <= 64 scan, whose lists leave room for
+//  four blocks per CU; the bias / scale modes and K > 64 need more registers than that)
 template <int KH, int MODE>
-__global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const float *fu, const float *fi, const float *cu,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? (MODE == 0 ? 4 : 3) : 2))) void topk_fused_kernel(TopkParams p, const float *fu, const float *fi, const float *cu,
                                                          const float *ci, int k, int nbuf, int64_t seg_items, int nseg,
                                                          float *cand_val, int32_t *cand_idx, int32_t *out_items,
                                                          double *out_scores) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         ucst[r] = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
         if (MODE != 0 && qq < p.nq) ucst[r] = cu[p.users[qq]];
     }
-    for (int e = lane; e < 32 * k; e += 64) le[e] = 0ull;   // empty entries: the key below every score's
+    for (int e = lane; e < 32 * k; e += 64) le[e] = TOPK_EMPTY_KEY;
 
     // Loads are unconditional (no branch, nothing for the loop's wait counters to merge): a row past the
     // segment's end re-reads the last row (its scores are never ranked), a piece past Kpad re-reads the
@@ -384,41 +387,43 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
             stage[(size_t)buf * ST * PQ + (idx / PR) * PQ + idx % PR] = g[j];
         }
     };
-    // insert (v, item) into the list of local user `ul`; returns that list's new k-th best value (its bits).  Lane e holds entry e.
-    // An entry is one 64-bit key, (score bits made monotone) << 32 | ~item: a bigger key ranks first, so the candidate's
-    // place is ONE 64-bit compare and a ballot, its key is built with scalar instructions and dropped into its lane with
-    // v_writelane, and the entries behind it move down one lane (DPP).  Nine vector instructions and one LDS round trip --
-    // the (score, item) pair compare this replaces took about 25, and the vector ALU's cycles are the matrix pipe's.
+    // insert the candidate (score bits vb, ~item) into the list of local user `ul`; returns that list's new k-th best value
+    // (its bits).  Lane e holds entry e.  An entry is one 64-bit key, (score bits made monotone) << 32 | ~item: a bigger key
+    // ranks first, so the candidate's place is ONE 64-bit compare and a ballot, its key is built with scalar instructions
+    // and dropped into its lane with v_writelane, and the entries behind it move down one lane by DPP under an EXEC mask
+    // the scalar unit derives from the ballot.  EVERY instruction counts here, scalar ones as much as vector ones: beside
+    // waves that stream MFMAs an instruction of a ranking wave costs the SIMD about five cycles whatever unit runs it
+    // (profiles/r03_topk_instruction_cost.log) -- hence the one asm block (no EXEC save / restore pairs, no branch
+    // around the masked store, lane select straight from an SGPR, both words stored by one ds_write2).
     const unsigned long long kmask = k >= 64 ? ~0ull : (1ull << k) - 1;   // the lanes that hold list entries
-    auto insert = [&](int ul, float v, int item) __attribute__((always_inline)) -> unsigned {
-        unsigned vb = __float_as_uint(v);
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const unsigned le_lane = (unsigned)(size_t)(lds_u64 *)(le + lane);    // LDS byte address of this lane's entry of list 0
+    auto insert = [&](int ul, unsigned vb, unsigned nitem) __attribute__((always_inline)) -> unsigned {
         if (vb == 0x80000000u) vb = 0u;                              // -0.0 ranks as +0.0 does
         const unsigned ov = vb ^ ((unsigned)((int)vb >> 31) | 0x80000000u);
-        const unsigned nitem = ~(unsigned)item;
         const unsigned long long ck = ((unsigned long long)ov << 32) | nitem;
-        unsigned long long *ue = le + ul * k;
         // (every lane reads: past entry k - 1 it is the next lists' entries, or the padding behind the last one; they are
         //  masked out of the ballot and never written back -- no divergent region, the k-th entry is read as a scalar)
-        const unsigned long long e = ue[lane];
+        const unsigned long long e = le[ul * k + lane];
         unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
         const int pos = __popcll(__builtin_amdgcn_ballot_w64(e > ck) & kmask);   // entries that rank before the candidate
         if (pos < k) {                                               // (an earlier candidate of this tile may have filled the list)
-            // the entries from `pos` on move down one lane: EXEC is cut to those lanes with scalar instructions and the
-            // DPP moves run in place (lane pos has no active source and keeps its entry until the writelane).  A lane
-            // compare and two selects would do the same with three more vector instructions.
-            const unsigned long long from = ~0ull << pos;
-            unsigned long long saved;
-            asm volatile("s_mov_b64 %[sv], exec\n\t"
-                         "s_mov_b64 exec, %[from]\n\t"
+            // lanes >= pos take the entry of the lane below (lane pos has no active source: it keeps its entry until the
+            // writelane), the candidate goes into lane pos, lanes < k store.  EXEC is all ones here (no divergent region).
+            asm volatile("s_mov_b32 m0, %[pos]\n\t"               // (one SGPR per vector instruction: the lane select rides in M0,
+                         "s_mov_b64 exec, %[from]\n\t"             //  which nothing else in this kernel uses -- tests/test_abi_cpu.py)
                          "s_nop 4\n\t"
                          "v_mov_b32_dpp %[lo], %[lo] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                          "v_mov_b32_dpp %[hi], %[hi] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_mov_b64 exec, %[sv]"
-                         : [lo] "+v"(lo), [hi] "+v"(hi), [sv] "=&s"(saved)
-                         : [from] "s"(from));
-            lo = (unsigned)pmf_writelane((int)nitem, pos, (int)lo);
-            hi = (unsigned)pmf_writelane((int)ov, pos, (int)hi);
-            if (lane < k) ue[lane] = ((unsigned long long)hi << 32) | lo;
+                         "s_mov_b64 exec, %[kmask]\n\t"
+                         "v_writelane_b32 %[lo], %[nitem], m0\n\t"
+                         "v_writelane_b32 %[hi], %[ov], m0\n\t"
+                         "ds_write2_b32 %[addr], %[lo], %[hi] offset1:1\n\t"
+                         "s_mov_b64 exec, -1"
+                         : [lo] "+v"(lo), [hi] "+v"(hi)
+                         : [from] "s"(~0ull << pos), [kmask] "s"(kmask), [nitem] "s"(nitem), [ov] "s"(ov), [pos] "s"(pos),
+                           [addr] "v"(le_lane + (unsigned)(ul * k) * 8u)
+                         : "memory");
         }
         const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)hi, k - 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -466,27 +471,34 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
     // keep the lower item id in front
     auto drain = [&](int64_t i0, const f32x16 &acc, const unsigned long long (&mk)[16], unsigned long long okm)
                      __attribute__((always_inline)) {
+        const unsigned ni0 = ~(unsigned)i0;           // ~(i0 + j) == ~i0 - j
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             unsigned long long m = mk[r] & okm;
             while (m) {
                 const int L = __builtin_ctzll(m);
-                m &= m - 1;
+                asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(L));
                 const int hh = L >> 5;
+                // (a row past the last query user never gets here: its threshold is +inf -- and if an infinite score did
+                //  bring it here, the list it lands in exists in LDS and is never handed over)
                 const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (q0 + ul >= p.nq) continue;
-                const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[r]), L));
+                const unsigned vb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(acc[r]), L);
+#ifdef PMF_TOPK_PAD_SCALAR   // (diagnostic: what an extra scalar / vector instruction per candidate costs the launch --
+#pragma unroll                // profiles/r03_topk_instruction_cost.log: about five cycles of SIMD time each, either kind)
+                for (int pad = 0; pad < PMF_TOPK_PAD_SCALAR; ++pad) { int d_; asm volatile("s_mov_b32 %0, 0" : "=s"(d_)); }
+#endif
+#ifdef PMF_TOPK_PAD_VECTOR
+#pragma unroll
+                for (int pad = 0; pad < PMF_TOPK_PAD_VECTOR; ++pad) { int d_; asm volatile("v_mov_b32 %0, 0" : "=v"(d_)); }
+#endif
                 // (an earlier candidate of this tile may have raised the list's threshold past v: insert() re-checks)
-                const unsigned nt = insert(ul, v, (int)(i0 + (L & 31)));
+                const unsigned nt = insert(ul, vb, ni0 - (unsigned)(L & 31));
                 // tau[r] = nt in the half-wave (h == hh) that holds this user's row: one v_mov under a scalar EXEC
-                const unsigned long long half = 0xffffffffull << (32 * hh);
-                unsigned long long saved;
-                asm volatile("s_mov_b64 %[sv], exec\n\t"
-                             "s_mov_b64 exec, %[half]\n\t"
+                asm volatile("s_mov_b64 exec, %[half]\n\t"
                              "v_mov_b32 %[t], %[nt]\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [t] "+v"(tau[r]), [sv] "=&s"(saved)
-                             : [half] "s"(half), [nt] "s"(nt));
+                             "s_mov_b64 exec, -1"
+                             : [t] "+v"(tau[r])
+                             : [half] "s"(0xffffffffull << (32 * hh)), [nt] "s"(nt));
             }
         }
     };
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(TopkParams p, const flo
         if (qq >= p.nq) continue;
         const unsigned long long ent = le[e];
         const float v = topk_key_score((unsigned)(ent >> 32));
-        const int idx = ent == 0ull ? 0x7fffffff : (int)~(unsigned)ent;
+        const int idx = (unsigned)ent == 0u ? 0x7fffffff : (int)~(unsigned)ent;
         if (nseg == 1) {
             out_items[(int64_t)qq * k + t] = idx == 0x7fffffff ? -1 : idx;
             out_scores[(int64_t)qq * k + t] = idx == 0x7fffffff ? 0.0 : (double)v;
@@ -660,7 +672,8 @@ static hipError_t launch_topk_fused_mode(pmf_ctx *ctx, const TopkParams &p, dim3
     // persistent in x: at most as many blocks as are resident at once (the occupancy query x CUs), each walking its
     // share of the 128-user tiles; with a segmented item range (few users) every (tile, segment) keeps its own block
     if (grid.y == 1) {
-        const unsigned resident = (unsigned)std::max(1, nbuf == 2 ? per_cu2 : per_cu1) * (unsigned)std::max(1, cus);
+        unsigned resident = (unsigned)std::max(1, nbuf == 2 ? per_cu2 : per_cu1) * (unsigned)std::max(1, cus);
+        if (ctx->topk_max_blocks > 0) resident = std::min(resident, (unsigned)ctx->topk_max_blocks);   // (tests: few blocks, many tiles each)
         if (grid.x > resident) grid.x = resident;
     }
     hipLaunchKernelGGL((topk_fused_kernel<KH, MODE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, nbuf,

@@ -166,6 +166,12 @@ def test_hot_kernels_do_not_spill_and_use_the_intended_instructions(device_asm):
     assert body.count("v_mfma_f32_16x16x4_f32") >= 32 and body.count("v_mfma_f32_32x32x2_f32") >= 5
     assert "v_mfma_f32_32x32x2_f32" in device_asm["pmf_topk"]
     assert "s_setprio" in device_asm["pmf_topk"]             # the time-sliced wave priority of the fused top-k scan
+    # the list insertion's inline asm carries its v_writelane lane select in M0 behind the compiler's back: nothing the
+    # compiler emits in that translation unit may use M0
+    topk = device_asm["pmf_topk"]
+    assert "ds_write2_b32" in topk and "v_cmp_lt_u64" in topk
+    foreign = [l for l in topk.splitlines() if re.search(r"\bm0\b", l) and not re.match(r"\s*(;|s_mov_b32 m0, s\d+$|v_writelane_b32 v\d+, s\d+, m0$)", l)]
+    assert not foreign, foreign[:5]
     gamma = device_asm["pmf_gamma"]
     assert "row_half_mirror" in gamma and "row_mirror" in gamma and "quad_perm" in gamma
     assert "global_atomic" not in gamma and "global_atomic" not in gauss   # deterministic: no atomics anywhere

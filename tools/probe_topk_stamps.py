@@ -64,4 +64,7 @@ for label, beta in (("random item factors", rng.gamma(0.5, 1.0, (I, K))),
                           "cycles_at_stage_barriers_mean": round(float(raw[:, 5].mean())),
                           "candidates_per_wave_scan_mean": round(float(raw[:, 6].mean()), 1),
                           "tiles_with_candidates_mean": round(float(raw[:, 7].mean()), 1),
-                          "scan_cycles_at_2.39GHz_median": round(float(np.median(end - begin)) * 2390)}), flush=True)
+                          "scan_cycles_at_2.39GHz_median": round(float(np.median(end - begin)) * 2390),
+                          # when the (last recorded) scans of the user tiles begin: ms -> number of wavefronts
+                          "scan_begin_ms_histogram": {str(b): int(n) for b, n in zip(*np.unique(np.round(begin / 1000.0), return_counts=True))},
+                          "xcc_of_blocks_0_256_512_768": [int(raw[(b * 4) % len(raw), 3]) for b in (0, 256, 512, 768)]}), flush=True)

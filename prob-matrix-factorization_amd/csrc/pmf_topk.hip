@@ -8,6 +8,7 @@
 // (each pass = strided scan + wave arg-max restricted to entries ranked after
 // the previous pick), which is deterministic and needs no sorting network.
 #include <algorithm>
+#include <climits>
 #include <type_traits>
 
 #include "pmf_device.h"
@@ -291,13 +292,14 @@ struct TopkStage {
 
 // (waves per SIMD the register allocation must leave room for: four for the plain K <= 64 scan, whose lists leave room for
 //  four blocks per CU; the bias / scale modes and K > 64 need more registers than that)
-template <int KH, int MODE>
+template <int KH, int MODE, int NBUF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? (MODE == 0 ? 4 : 3) : 2))) void topk_fused_kernel(TopkParams p, const float *fu, const float *fi, const float *cu,
-                                                         const float *ci, int k, int nbuf, int64_t seg_items, int nseg,
+                                                         const float *ci, int k, int64_t seg_items, int nseg,
                                                          float *cand_val, int32_t *cand_idx, int32_t *out_items,
                                                          double *out_scores) {
     using S = TopkStage<KH>;
     constexpr int ST = S::ST, PR = S::PR, PQ = S::PQ, LPT = S::LPT;
+    constexpr int nbuf = NBUF;                        // stage buffers: two, or one where that keeps another block on the CU
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // (readfirstlane: the wave index is uniform, and the compiler only knows it once told -- what hangs off q0 then
     //  branches on SCC instead of masking exec)
@@ -307,8 +309,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? 
     // [32][k] list entries of this wave's users, best first: 64-bit keys (insert() below)
     unsigned long long *le = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * S::buffer_bytes) + (size_t)wave * 32 * k;
     const int seg = blockIdx.y;
-    const int64_t i_begin = (int64_t)seg * seg_items;
-    const int64_t i_end = i_begin + seg_items < p.n_items ? i_begin + seg_items : p.n_items;
+    // (item indices are ints in here -- the host sends more than 2^31 - 64 items to the two-phase path: 64-bit compares
+    //  have no scalar form, and every instruction of this loop is paid for)
+    const int i_begin = (int)((int64_t)seg * seg_items);
+    const int i_end = (int)((int64_t)i_begin + seg_items < p.n_items ? (int64_t)i_begin + seg_items : p.n_items);
     const int kpad = p.kpad;
 
     // PERSISTENT blocks: the grid is sized to what the chip holds at once (launch_topk_fused_mode) and a block walks
@@ -355,29 +359,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? 
     //  row-address arithmetic per stage, and the scalar masks in the threshold test below.)
     f32x4 g[LPT];
     const int last_piece = kpad / 4 - 1;
-    const char *gp[LPT];                              // this thread's pieces of the stage fetched next (full stages)
+    // full stages: one scalar base for the block, advanced per stage, plus this thread's constant 32-bit byte offsets
+    // (global_load with an SGPR base: no per-thread pointer arithmetic in the loop)
+    const char *next_stage = reinterpret_cast<const char *>(fi + (int64_t)i_begin * kpad);
+    const unsigned stage_bytes = (unsigned)ST * kpad * 4;
+    unsigned goff[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         const int idx = j * 256 + (int)threadIdx.x;
         const int r = idx / PR, pc = idx % PR;
-        gp[j] = reinterpret_cast<const char *>(fi + (i_begin + r) * kpad + 4 * (pc < last_piece ? pc : last_piece));
+        goff[j] = ((unsigned)r * kpad + 4u * (pc < last_piece ? pc : last_piece)) * 4u;
     }
-    const int64_t stage_bytes = (int64_t)ST * kpad * 4;
-    auto fetch = [&](int64_t i0) __attribute__((always_inline)) {   // (out of line, g[] would live in scratch)
-        if (i0 + ST <= i_end) {                       // wave-uniform: every row of the stage exists
+    auto fetch_full = [&]() __attribute__((always_inline)) {          // (out of line, g[] would live in scratch)
 #pragma unroll
-            for (int j = 0; j < LPT; ++j) {
-                g[j] = *reinterpret_cast<const f32x4 *>(gp[j]);
-                gp[j] += stage_bytes;
-            }
-        } else {                                      // the segment's last, partial stage
+        for (int j = 0; j < LPT; ++j) g[j] = *reinterpret_cast<const f32x4 *>(next_stage + goff[j]);
+        next_stage += stage_bytes;
+    };
+    auto fetch_tail = [&](int i0) __attribute__((always_inline)) {    // the segment's last, partial stage
 #pragma unroll
-            for (int j = 0; j < LPT; ++j) {
-                const int idx = j * 256 + (int)threadIdx.x;
-                const int r = idx / PR, pc = idx % PR;
-                const int64_t it = i0 + r < i_end ? i0 + r : i_end - 1;
-                g[j] = *reinterpret_cast<const f32x4 *>(fi + it * kpad + 4 * (pc < last_piece ? pc : last_piece));
-            }
+        for (int j = 0; j < LPT; ++j) {
+            const int idx = j * 256 + (int)threadIdx.x;
+            const int r = idx / PR, pc = idx % PR;
+            const int it = i0 + r < i_end ? i0 + r : i_end - 1;
+            g[j] = *reinterpret_cast<const f32x4 *>(fi + (int64_t)it * kpad + 4 * (pc < last_piece ? pc : last_piece));
         }
     };
     auto stash = [&](int buf) __attribute__((always_inline)) {
@@ -445,39 +449,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b.w, acc, 0, 0, 0);
         }
     };
-    // dot products -> scores; the 16 threshold compares leave their lane masks in SGPRs (v_cmp -> s[..]): everything
-    // that follows until a candidate is actually inserted is scalar, no vector instruction competes with the other
-    // waves' MFMAs.  Returns whether any score of an existing item reaches its user's list.
-    auto thresholds = [&](int64_t i0, f32x16 &acc, unsigned long long (&mk)[16], unsigned long long &okm)
-                          __attribute__((always_inline)) -> bool {
-        const int64_t it = i0 + c;
-        const bool ok = it < i_end;
+    // dot products -> scores (predict's arithmetic order); TAIL: the stage holds rows past the segment's end
+    auto scores = [&](auto TAIL, int i0, f32x16 &acc) __attribute__((always_inline)) {
+        if (MODE == 0) return;
+        const int it = i0 + c;
         float ccst = MODE == PMF_PREDICT_SCALE ? 1.f : 0.f;
-        if (MODE != 0 && ok) ccst = ci[it];
-        unsigned long long anym = 0ull;
+        if (!decltype(TAIL)::value || it < i_end) ccst = ci[it];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float sc = acc[r];
-            if (MODE == PMF_PREDICT_BIAS) sc = ucst[r] + ccst + sc;          // predict's order: b_u + b_i + dot
-            if (MODE == PMF_PREDICT_SCALE) sc = sc * (ucst[r] * ccst);
-            acc[r] = sc;
-            mk[r] = __builtin_amdgcn_ballot_w64(sc >= tau[r]);
-            anym |= mk[r];
+            if (MODE == PMF_PREDICT_BIAS) acc[r] = ucst[r] + ccst + acc[r];  // b_u + b_i + dot
+            if (MODE == PMF_PREDICT_SCALE) acc[r] = acc[r] * (ucst[r] * ccst);
         }
-        okm = __builtin_amdgcn_ballot_w64(ok);
-        return (anym & okm) != 0ull;
+    };
+    // Does any score of the tile reach its user's list?  Almost never (a list changes ~k ln(N / k) times in N items), so
+    // the test itself is what a tile pays: 16 v_cmpx narrow EXEC to the lanes whose rows are ALL below their thresholds
+    // -- no mask per row, no OR chain (16 scalar instructions the compare-and-collect form needs) -- and two scalar
+    // instructions see whether that is every lane.  (Two asm blocks: an asm statement takes 30 operands.  Each leaves
+    // EXEC as it found it.  The s_nop pair is the MFMA -> VALU read distance the compiler cannot see into an asm for.)
+    auto all_below = [&](const f32x16 &acc, unsigned long long &m1, unsigned long long &m2) __attribute__((always_inline)) -> bool {
+        asm volatile("s_nop 15\n\ts_nop 3\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a0], %[t0]\n\tv_cmpx_lt_f32 vcc, %[a1], %[t1]\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a2], %[t2]\n\tv_cmpx_lt_f32 vcc, %[a3], %[t3]\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a4], %[t4]\n\tv_cmpx_lt_f32 vcc, %[a5], %[t5]\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a6], %[t6]\n\tv_cmpx_lt_f32 vcc, %[a7], %[t7]\n\t"
+                     "s_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
+                     : [m] "=s"(m1)
+                     : [a0] "v"(acc[0]), [t0] "v"(tau[0]), [a1] "v"(acc[1]), [t1] "v"(tau[1]), [a2] "v"(acc[2]), [t2] "v"(tau[2]),
+                       [a3] "v"(acc[3]), [t3] "v"(tau[3]), [a4] "v"(acc[4]), [t4] "v"(tau[4]), [a5] "v"(acc[5]), [t5] "v"(tau[5]),
+                       [a6] "v"(acc[6]), [t6] "v"(tau[6]), [a7] "v"(acc[7]), [t7] "v"(tau[7])
+                     : "vcc");
+        asm volatile("v_cmpx_lt_f32 vcc, %[a0], %[t0]\n\tv_cmpx_lt_f32 vcc, %[a1], %[t1]\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a2], %[t2]\n\tv_cmpx_lt_f32 vcc, %[a3], %[t3]\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a4], %[t4]\n\tv_cmpx_lt_f32 vcc, %[a5], %[t5]\n\t"
+                     "v_cmpx_lt_f32 vcc, %[a6], %[t6]\n\tv_cmpx_lt_f32 vcc, %[a7], %[t7]\n\t"
+                     "s_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
+                     : [m] "=s"(m2)
+                     : [a0] "v"(acc[8]), [t0] "v"(tau[8]), [a1] "v"(acc[9]), [t1] "v"(tau[9]), [a2] "v"(acc[10]), [t2] "v"(tau[10]),
+                       [a3] "v"(acc[11]), [t3] "v"(tau[11]), [a4] "v"(acc[12]), [t4] "v"(tau[12]), [a5] "v"(acc[13]), [t5] "v"(tau[13]),
+                       [a6] "v"(acc[14]), [t6] "v"(tau[14]), [a7] "v"(acc[15]), [t7] "v"(tau[15])
+                     : "vcc");
+        return (m1 & m2) == ~0ull;
+    };
+    // the 16 threshold compares with their lane masks left in SGPRs (v_cmp -> s[..]): the scan for candidates is scalar
+    auto thresholds = [&](int r0, int r1, const f32x16 &acc, unsigned long long (&mk)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r >= r0 && r < r1) mk[r] = __builtin_amdgcn_ballot_w64(acc[r] >= tau[r]);
     };
     // the tile's candidates go into their lists in ascending item order (lane order within the tile), so equal scores
     // keep the lower item id in front
-    auto drain = [&](int64_t i0, const f32x16 &acc, const unsigned long long (&mk)[16], unsigned long long okm)
+    auto drain = [&](int r0, int r1, int i0, const f32x16 &acc, const unsigned long long (&mk)[16], unsigned long long okm)
                      __attribute__((always_inline)) {
         const unsigned ni0 = ~(unsigned)i0;           // ~(i0 + j) == ~i0 - j
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if (r < r0 || r >= r1) continue;
             unsigned long long m = mk[r] & okm;
             while (m) {
                 const int L = __builtin_ctzll(m);
                 asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(L));
+#ifdef PMF_TOPK_STAMPS
+                ++st_cand;
+#endif
                 const int hh = L >> 5;
                 // (a row past the last query user never gets here: its threshold is +inf -- and if an infinite score did
                 //  bring it here, the list it lands in exists in LDS and is never handed over)
@@ -518,54 +551,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? 
     auto rotate_priority = [&](int stage_no) __attribute__((always_inline)) {
         if ((stage_no & (PRIO_SLICE - 1)) == 0) slice_priority(stage_no);
     };
-    auto tile = [&](int64_t i0, const f32x4 *rows, int stage_no) __attribute__((always_inline)) {
+    auto tile = [&](auto TAIL, int i0, const f32x4 *rows, int stage_no) __attribute__((always_inline)) {
         f32x16 acc;
         unsigned long long mk[16], okm;
         mfma_all(rows, acc);
-        if (thresholds(i0, acc, mk, okm)) {
+        scores(TAIL, i0, acc);
+        // which half of the rows holds a candidate (the v_cmpx blocks' lane masks); a partial tile takes both
+        unsigned long long m1 = 0ull, m2 = 0ull;
+        if (!decltype(TAIL)::value && all_below(acc, m1, m2)) return;
+        okm = decltype(TAIL)::value ? __builtin_amdgcn_ballot_w64(i0 + c < i_end) : ~0ull;
 #ifdef PMF_TOPK_STAMPS
-            const long long t_ = __builtin_amdgcn_s_memtime();
-            for (int r = 0; r < 16; ++r) st_cand += __builtin_popcountll(mk[r] & okm);
-            ++st_tiles;
+        const long long t_ = __builtin_amdgcn_s_memtime();
+        ++st_tiles;
 #endif
 #ifdef PMF_TOPK_RANK_PRIORITY   // (experiment: rank at the top priority, then step back to the time slice's -- no gain)
-            __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);
 #endif
-            drain(i0, acc, mk, okm);
+        if (m1 != ~0ull) {
+            thresholds(0, 8, acc, mk);
+            drain(0, 8, i0, acc, mk, okm);
+        }
+        if (m2 != ~0ull) {
+            thresholds(8, 16, acc, mk);
+            drain(8, 16, i0, acc, mk, okm);
+        }
 #ifdef PMF_TOPK_RANK_PRIORITY
-            slice_priority(stage_no);
+        slice_priority(stage_no);
 #endif
 #ifdef PMF_TOPK_STAMPS
-            st_drain += __builtin_amdgcn_s_memtime() - t_;
+        st_drain += __builtin_amdgcn_s_memtime() - t_;
 #endif
+    };
+    auto tiles = [&](auto TAIL, int i0, const f32x4 *rows, int stage_no) __attribute__((always_inline)) {
+        if (!active) return;                          // a wave without users only stages item rows
+        tile(TAIL, i0, rows, stage_no);
+        if (ST == 64 && (!decltype(TAIL)::value || i0 + 32 < i_end)) tile(TAIL, i0 + 32, rows + 32 * PQ, stage_no);
+    };
+    // the stage in g[] becomes the one the block multiplies next (every wave runs the same stages: the barriers)
+    int buf = 0;
+    auto publish = [&]() __attribute__((always_inline)) {
+        if (nbuf == 2) {
+            stash(buf ^ 1);                           // last read there: the stage before this one, behind the barrier
+            STAMP_BARRIER();
+            buf ^= 1;
+        } else {                                      // one buffer (long lists: the LDS saved keeps another block resident)
+            STAMP_BARRIER();                          // every wave has read this stage
+            stash(0);
+            STAMP_BARRIER();
         }
     };
-    // every wave of the block runs the same number of stages (the barriers below)
-    int buf = 0, stage_no = 0;
-    fetch(i_begin);                                   // (segments are never empty)
+    // The loop proper has no case to tell apart: it runs while the stage after the current one is a full one; the
+    // segment's last full stage and its partial one (rows past the end re-read the last row and are never ranked) follow.
+    const int n_full = (i_end - i_begin) / ST;
+    const bool has_tail = (i_end - i_begin) % ST != 0;
+    const std::integral_constant<bool, false> FULL;
+    const std::integral_constant<bool, true> PARTIAL;
+    int stage_no = 0, i0 = i_begin;
+    if (n_full > 0) fetch_full(); else fetch_tail(i_begin);            // (segments are never empty)
     stash(0);
     __syncthreads();
-    {
-        for (int64_t i0 = i_begin; i0 < i_end; i0 += ST, ++stage_no) {
-            const bool more = i0 + ST < i_end;
-            rotate_priority(stage_no);
-            if (more) fetch(i0 + ST);
-            const f32x4 *rows = stage + (size_t)buf * ST * PQ;
-            if (active) {
-                tile(i0, rows, stage_no);
-                if (ST == 64 && i0 + 32 < i_end) tile(i0 + 32, rows + 32 * PQ, stage_no);
-            }
-            if (nbuf == 2) {
-                if (more) stash(buf ^ 1);             // last read there: the stage before this one, behind the barrier
-                STAMP_BARRIER();
-                buf ^= 1;
-            } else {                                  // one buffer (long lists: the LDS saved keeps another block resident)
-                STAMP_BARRIER();                      // every wave has read this stage
-                if (more) stash(0);
-                STAMP_BARRIER();
-            }
+    const int n_steady = n_full > 0 ? n_full - 1 : 0;
+    for (int s0 = 0; s0 < n_steady; s0 += PRIO_SLICE) {               // (one priority slice per trip: nothing to test per stage)
+        slice_priority(s0);
+        const int s1 = s0 + PRIO_SLICE < n_steady ? s0 + PRIO_SLICE : n_steady;
+        for (int st = s0; st < s1; ++st, i0 += ST) {
+            fetch_full();
+            tiles(FULL, i0, stage + (size_t)buf * ST * PQ, st);
+            publish();
         }
     }
+    stage_no = n_steady;
+    if (n_full > 0) {
+        rotate_priority(stage_no);
+        if (has_tail) fetch_tail(i0 + ST);
+        tiles(FULL, i0, stage + (size_t)buf * ST * PQ, stage_no);
+        if (has_tail) publish();
+        ++stage_no;
+        i0 += ST;
+    }
+    if (has_tail) tiles(PARTIAL, i0, stage + (size_t)buf * ST * PQ, stage_no);
+    STAMP_BARRIER();                                  // the next user tile's first stage goes where this one is read
     // hand the lists over: final result when the item range was not segmented, else this segment's candidates
     for (int e = lane; e < 32 * k; e += 64) {
         const int ul = e / k, t = e % k;
@@ -654,15 +719,16 @@ static hipError_t launch_topk_fused_mode(pmf_ctx *ctx, const TopkParams &p, dim3
     // 1 KB of LDS per k and block: from k = 23 at K = 64 the second buffer costs the CU a resident block
     // (profiles/r03_topk_long_lists.jsonl: 34.3 -> 30.8 ms at k = 24, 72.9 -> 49.3 ms at k = 64).  Take one buffer where
     // it keeps more blocks on the CU.  (ctx->topk_stage_buffers pins it: PMF_TOPK_STAGE_BUFFERS, for the probes.)
-    const void *fn = (const void *)topk_fused_kernel<KH, MODE>;
+    const void *fn2 = (const void *)topk_fused_kernel<KH, MODE, 2>, *fn1 = (const void *)topk_fused_kernel<KH, MODE, 1>;
     const size_t smem2 = 2 * TopkStage<KH>::buffer_bytes + list_bytes, smem1 = TopkStage<KH>::buffer_bytes + list_bytes;
     if (smem2 > (64u << 10)) {   // long lists at K > 64: past the default dynamic-LDS limit
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        hipError_t e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         if (e != hipSuccess) return e;
     }
     int per_cu2 = 0, per_cu1 = 0, dev = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, fn, 256, smem2);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, fn, 256, smem1);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, fn2, 256, smem2);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, fn1, 256, smem1);
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
@@ -676,8 +742,12 @@ static hipError_t launch_topk_fused_mode(pmf_ctx *ctx, const TopkParams &p, dim3
         if (ctx->topk_max_blocks > 0) resident = std::min(resident, (unsigned)ctx->topk_max_blocks);   // (tests: few blocks, many tiles each)
         if (grid.x > resident) grid.x = resident;
     }
-    hipLaunchKernelGGL((topk_fused_kernel<KH, MODE>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, nbuf,
-                       seg_items, nseg, cand_val, cand_idx, out_items, out_scores);
+    if (nbuf == 2)
+        hipLaunchKernelGGL((topk_fused_kernel<KH, MODE, 2>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
+                           nseg, cand_val, cand_idx, out_items, out_scores);
+    else
+        hipLaunchKernelGGL((topk_fused_kernel<KH, MODE, 1>), grid, dim3(256), smem, ctx->stream, p, fu, fi, cu, ci, k, seg_items,
+                           nseg, cand_val, cand_idx, out_items, out_scores);
     return hipSuccess;
 }
 
@@ -774,7 +844,7 @@ static int run_topk(pmf_ctx *ctx, int64_t n_query, const int32_t *user_ids, int 
     const T *bu = use_bias ? (const T *)ctx->arr[PMF_SIDE_USER][carr] : nullptr;
     const T *bi = use_bias ? (const T *)ctx->arr[PMF_SIDE_ITEM][carr] : nullptr;
     if constexpr (std::is_same<T, float>::value) {
-        if (ctx->kpad <= 128 && k <= 64 && !ctx->topk_two_phase)
+        if (ctx->kpad <= 128 && k <= 64 && I <= (int64_t)INT32_MAX - 64 && !ctx->topk_two_phase)   // (the fused scan counts items in ints)
             return run_topk_fused(ctx, n_query, user_ids, k, use_bias, bu, bi, out_items, out_scores);
     }
     // batch size: scores buffer of at most ~512 MB

@@ -176,3 +176,40 @@ def test_extended_poisson_top_k_follows_its_own_predict():
                                                             tol=None, verbose=False, **meta["base_cfg"]), dtype="f32").fit(train)
     it32, _ = m32.top_k_items(users, 10)      # the fused fp32 kernel, scale mode
     assert np.mean(it32 == items) > 0.97
+
+
+@pytest.mark.parametrize("max_blocks", [0, 2])
+@pytest.mark.parametrize("U,I,K,k", [(1, 1, 1, 1), (5, 7, 3, 7), (40, 31, 16, 31), (33, 32, 8, 1), (100, 33, 20, 33),
+                                      (64, 64, 64, 64), (130, 95, 128, 50), (257, 1000, 100, 64), (700, 63, 64, 10),
+                                      (515, 97, 40, 24), (129, 4097, 12, 3)])
+def test_fused_topk_edge_shapes_rank_like_numpy(U, I, K, k, max_blocks, monkeypatch):
+    """The fused fp32 kernel where its special paths begin and end: fewer items than one 32-item tile (only the partial
+    stage), exactly one tile, one item past a tile, k = the item count, k = 1 and k = 64, one user, user counts around the
+    32 / 128 tile edges; Gaussian factors (scores of both signs).  `max_blocks` = 2 makes two blocks walk all user tiles
+    (the persistent loop with many tiles per block).  Checked against a NumPy ranking of the device's own fp32 tables."""
+    import pmf_hip
+    from pmf_hip import ARR_FACTOR, ITEM, USER
+    if max_blocks:
+        monkeypatch.setenv("PMF_TOPK_MAX_BLOCKS", str(max_blocks))
+    rng = np.random.default_rng(U * 1000 + I)
+    A, B = rng.standard_normal((U, K)), rng.standard_normal((I, K))
+    if I > 8:
+        B[I - 1] = B[2]                       # an exact tie with the last item
+    users = rng.permutation(U)
+    with pmf_hip.Context(U, I, K, dtype="f32") as ctx:
+        ctx.set_array(USER, ARR_FACTOR, A); ctx.set_array(ITEM, ARR_FACTOR, B)
+        items, scores = ctx.topk_items(users, k)
+        full = ctx.get_array(USER, ARR_FACTOR)[users] @ ctx.get_array(ITEM, ARR_FACTOR).T
+    assert items.shape == (U, k) and (items >= 0).all() and (items < I).all()
+    assert all(len(set(row)) == k for row in items)                       # no item twice
+    # (signed products cancel: the fp32 sum's error is relative to sum |a_k b_k|, not to the score)
+    tol = 3e-7 * (np.abs(A[users]) @ np.abs(B).T).max() + 1e-6
+    np.testing.assert_allclose(scores, np.take_along_axis(full, items, axis=1), rtol=0, atol=tol)
+    assert (np.diff(scores, axis=1) <= 0).all()
+    tie = np.diff(scores, axis=1) == 0
+    assert (np.diff(items, axis=1)[tie] > 0).all()
+    want = _rank(full, k)
+    kth = np.take_along_axis(full, want[:, -1:], axis=1)
+    assert (np.take_along_axis(full, items, axis=1) >= kth - 2 * tol).all()
+    if k == I:
+        assert np.array_equal(np.sort(items, axis=1), np.tile(np.arange(I), (U, 1)))

@@ -372,7 +372,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 32 ? 
     }
     auto fetch_full = [&]() __attribute__((always_inline)) {          // (out of line, g[] would live in scratch)
 #pragma unroll
-        for (int j = 0; j < LPT; ++j) g[j] = *reinterpret_cast<const f32x4 *>(next_stage + goff[j]);
+        for (int j = 0; j < LPT; ++j) {
+            unsigned off = goff[j];
+            asm volatile("" : "+v"(off));             // (keeps the zero-extension in the loop: SGPR base + 32-bit VGPR offset)
+            g[j] = *reinterpret_cast<const f32x4 *>(next_stage + off);
+        }
         next_stage += stage_bytes;
     };
     auto fetch_tail = [&](int i0) __attribute__((always_inline)) {    // the segment's last, partial stage

@@ -169,7 +169,8 @@ def test_hot_kernels_do_not_spill_and_use_the_intended_instructions(device_asm):
     # the list insertion's inline asm carries its v_writelane lane select in M0 behind the compiler's back: nothing the
     # compiler emits in that translation unit may use M0
     topk = device_asm["pmf_topk"]
-    assert "ds_write2_b32" in topk and "v_cmp_lt_u64" in topk
+    assert "ds_write2_b32" in topk and "v_cmp_lt_u64" in topk and "v_cmpx_lt_f32" in topk   # list change, key compare, tile test
+    assert re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", topk)             # stage fetch: SGPR base + VGPR offset
     foreign = [l for l in topk.splitlines() if re.search(r"\bm0\b", l) and not re.match(r"\s*(;|s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$|v_writelane_b32 v\d+, (s\d+|vcc_lo|vcc_hi), m0$)", l)]
     assert not foreign, foreign[:5]
     gamma = device_asm["pmf_gamma"]
